@@ -1,0 +1,189 @@
+// bcm.cpp -- product-of-experts ("BCM") over the experts resident on one GPU.
+//
+// Mirrors class BCM (distributed_gp/BCM.h:2-27, BCM.cpp): K experts, each a full GP on its own rows,
+// the objective is the plain sum of the experts' log-likelihoods / gradients (BCM.cpp:153-198) and
+// the prediction is a product of experts with no prior-precision correction (BCM.cpp:45-62).
+// Every expert owns its HIP stream, so the evaluations of the experts on one GPU are all enqueued
+// before the first result is fetched and run concurrently; sums are taken in expert order on the
+// host so the result does not depend on completion order.
+#include <cmath>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/cugp.h"
+
+struct cugp_bcm {
+    std::vector<cugp_gp*> experts;
+    std::vector<int> rows;
+    int d = 0, device = 0;
+    double hp[3] = {0, 0, 0};
+};
+
+extern "C" {
+
+int cugp_bcm_create(int nexperts, const int* rows, int d, int device, cugp_bcm** out)
+{
+    if (!out || nexperts <= 0 || !rows || d <= 0) return CUGP_ERR_INVALID;
+    cugp_bcm* b = new (std::nothrow) cugp_bcm;
+    if (!b) return CUGP_ERR_NOMEM;
+    b->d = d;
+    b->device = device;
+    for (int k = 0; k < nexperts; k++) {
+        cugp_gp* g = nullptr;
+        int rc = cugp_create(rows[k], d, device, &g);
+        if (rc) { cugp_bcm_destroy(b); return rc; }
+        b->experts.push_back(g);
+        b->rows.push_back(rows[k]);
+    }
+    *out = b;
+    return CUGP_OK;
+}
+
+// BCM.cpp:85-110 -- expert k gets rows [k*floor(N/K), ...), the last one also the remainder
+int cugp_bcm_create_split(const double* X, const double* y, int N, int D, int K, int device, cugp_bcm** out)
+{
+    if (!X || !y || N <= 0 || D <= 0 || K <= 0 || K > N) return CUGP_ERR_INVALID;
+    std::vector<int> rows(K), off(K);
+    const int part = N / K;
+    int start = 0;
+    for (int k = 0; k < K; k++) {
+        off[k] = start;
+        rows[k] = (k == K - 1) ? (N - start) : part;
+        start += part;
+    }
+    int rc = cugp_bcm_create(K, rows.data(), D, device, out);
+    if (rc) return rc;
+    for (int k = 0; k < K; k++) {
+        rc = cugp_bcm_set_expert_data(*out, k, X + (size_t)off[k] * D, y + off[k]);
+        if (rc) { cugp_bcm_destroy(*out); *out = nullptr; return rc; }
+    }
+    return CUGP_OK;
+}
+
+int cugp_bcm_destroy(cugp_bcm* b)
+{
+    if (!b) return CUGP_OK;
+    for (cugp_gp* g : b->experts) cugp_destroy(g);
+    delete b;
+    return CUGP_OK;
+}
+
+int cugp_bcm_num_experts(const cugp_bcm* b, int* k)
+{
+    if (!b || !k) return CUGP_ERR_INVALID;
+    *k = (int)b->experts.size();
+    return CUGP_OK;
+}
+
+int cugp_bcm_expert(cugp_bcm* b, int k, cugp_gp** gp)
+{
+    if (!b || !gp || k < 0 || k >= (int)b->experts.size()) return CUGP_ERR_INVALID;
+    *gp = b->experts[k];
+    return CUGP_OK;
+}
+
+int cugp_bcm_set_expert_data(cugp_bcm* b, int k, const double* X, const double* y)
+{
+    if (!b || k < 0 || k >= (int)b->experts.size()) return CUGP_ERR_INVALID;
+    return cugp_set_data(b->experts[k], X, y);
+}
+
+int cugp_bcm_set_loghyper(cugp_bcm* b, const double hp[3])
+{
+    if (!b || !hp) return CUGP_ERR_INVALID;
+    for (int i = 0; i < 3; i++) b->hp[i] = hp[i];
+    for (cugp_gp* g : b->experts) {
+        int rc = cugp_set_loghyper(g, b->hp);
+        if (rc) return rc;
+    }
+    return CUGP_OK;
+}
+
+int cugp_bcm_get_loghyper(const cugp_bcm* b, double hp[3])
+{
+    if (!b || !hp) return CUGP_ERR_INVALID;
+    for (int i = 0; i < 3; i++) hp[i] = b->hp[i];
+    return CUGP_OK;
+}
+
+int cugp_bcm_loglik_grad(cugp_bcm* b, double* ll, double g[3], double* per_expert_ll)
+{
+    if (!b) return CUGP_ERR_INVALID;
+    for (cugp_gp* e : b->experts) {                      // all experts in flight before the first fetch
+        int rc = cugp_loglik_grad_enqueue(e, 1);
+        if (rc) return rc;
+    }
+    double sll = 0.0, sg[3] = {0, 0, 0};
+    for (size_t k = 0; k < b->experts.size(); k++) {
+        double l, gk[3];
+        int rc = cugp_loglik_grad_fetch(b->experts[k], &l, gk);
+        if (rc) return rc;
+        sll = sll + l;                                   // BCM.cpp:190-194
+        for (int i = 0; i < 3; i++) sg[i] = (k == 0) ? gk[i] : sg[i] + gk[i];   // BCM.cpp:161-173
+        if (per_expert_ll) per_expert_ll[k] = l;
+    }
+    if (ll) *ll = sll;
+    if (g)
+        for (int i = 0; i < 3; i++) g[i] = sg[i];
+    return CUGP_OK;
+}
+
+int cugp_bcm_predict_partial(cugp_bcm* b, const double* Xt, int nt, double* sum_prec, double* sum_prec_mean)
+{
+    if (!b || !Xt || nt <= 0 || !sum_prec || !sum_prec_mean) return CUGP_ERR_INVALID;
+    std::vector<double> m(nt), v(nt);
+    for (int i = 0; i < nt; i++) sum_prec[i] = sum_prec_mean[i] = 0.0;
+    for (cugp_gp* e : b->experts) {
+        int rc = cugp_predict(e, Xt, nt, m.data(), v.data());
+        if (rc) return rc;
+        for (int i = 0; i < nt; i++) {                   // BCM.cpp:51-55
+            const double inv = 1.0 / v[i];
+            sum_prec[i] += inv;
+            sum_prec_mean[i] += inv * m[i];
+        }
+    }
+    return CUGP_OK;
+}
+
+int cugp_poe_finish(const double* sum_prec, const double* sum_prec_mean, int nt, double* mean, double* var)
+{
+    if (!sum_prec || !sum_prec_mean || !mean || !var || nt <= 0) return CUGP_ERR_INVALID;
+    for (int i = 0; i < nt; i++) {                       // BCM.cpp:56-60
+        const double tv = 1.0 / sum_prec[i];
+        var[i] = tv;
+        mean[i] = tv * sum_prec_mean[i];
+    }
+    return CUGP_OK;
+}
+
+int cugp_bcm_predict(cugp_bcm* b, const double* Xt, int nt, double* mean, double* var)
+{
+    if (!b || nt <= 0) return CUGP_ERR_INVALID;
+    std::vector<double> sp(nt), spm(nt);
+    int rc = cugp_bcm_predict_partial(b, Xt, nt, sp.data(), spm.data());
+    if (rc) return rc;
+    return cugp_poe_finish(sp.data(), spm.data(), nt, mean, var);
+}
+
+namespace {
+void bcm_objective(void* ctx, const double th[3], double* f, double g[3])
+{
+    cugp_bcm* b = (cugp_bcm*)ctx;
+    double ll = NAN;
+    cugp_bcm_set_loghyper(b, th);
+    if (cugp_bcm_loglik_grad(b, &ll, g, nullptr) != CUGP_OK) { ll = NAN; g[0] = g[1] = g[2] = NAN; }
+    *f = -1.0 * ll;
+}
+}  // namespace
+
+int cugp_bcm_cg_solve(cugp_bcm* b, int budget, double* trace, int trace_cap, int* nevals)
+{
+    if (!b) return CUGP_ERR_INVALID;
+    double th[3] = {b->hp[0], b->hp[1], b->hp[2]};
+    int rc = cugp_cg_minimize(bcm_objective, b, th, budget, trace, trace_cap, nevals);
+    if (rc) return rc;
+    return cugp_bcm_set_loghyper(b, th);
+}
+
+}  // extern "C"

@@ -1,0 +1,762 @@
+// cugp_capi.cpp -- the C-ABI (include/cugp.h) over the gfx950 kernels.
+//
+// One cugp_gp owns every device buffer of one expert (the reference keeps them as file-scope
+// globals, cuda_scalingdist/cuda_gp.cu:20-95, or as Covsum members, covkernel.h:6-18) and one HIP
+// stream on which all of its work is ordered.  Layout in HBM (npad = ceil(n/128)*128, row-major):
+//   X     n x d              inputs as given
+//   y     npad               labels, zero padded
+//   A     npad x npad        K (lower tiles), overwritten by its Cholesky factor L
+//   T     npad x npad        L^-1 (lower tiles; strictly-upper tiles are scratch of the inverse)
+//   U     npad x npad        L^-T (upper tiles) -- the row-major operand of K^-1 = U U^T
+//   Kinv  npad x npad        K^-1 (lower tiles, diagonal tiles complete)
+// T, U, Kinv are allocated on first use (gradient / prediction), A on first evaluation.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/cugp.h"
+#include "kernels.h"
+
+using namespace cugp;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* what, hipError_t e = hipSuccess)
+{
+    char buf[512];
+    if (e != hipSuccess) snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    else snprintf(buf, sizeof buf, "%s", what);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(call)                                                        \
+    do {                                                                    \
+        hipError_t e_ = (call);                                             \
+        if (e_ != hipSuccess) return fail(e_ == hipErrorOutOfMemory ? CUGP_ERR_NOMEM : CUGP_ERR_DEVICE, #call, e_); \
+    } while (0)
+
+constexpr int NPHASE = 6;
+constexpr int MAX_KEV = 4096;   // per-launch event pairs kept between resets
+
+}  // namespace
+
+struct cugp_gp {
+    int n = 0, d = 0, npad = 0, nt = 0, device = 0;
+    hipStream_t stream = nullptr;
+    double *dX = nullptr, *dy = nullptr, *dA = nullptr, *dT = nullptr, *dU = nullptr, *dKinv = nullptr;
+    double *dz = nullptr, *dalpha = nullptr, *dw = nullptr, *d16 = nullptr, *dlogdet = nullptr, *dpart = nullptr;
+    double* dout = nullptr;
+    double* hout = nullptr;        // pinned, 8 doubles
+    int nblocks_trace = 0;
+    double hp[3] = {0, 0, 0};
+    bool have_data = false;
+    bool factor_valid = false;     // A holds L for (data, hp)
+    bool inverse_valid = false;    // T, U, Kinv, alpha hold the inverse quantities for (data, hp)
+    bool pending = false, pending_grad = false;
+    double last_ll = NAN, last_g[3] = {NAN, NAN, NAN}, last_quad = NAN, last_logdet = NAN;
+    // profiling
+    int prof = 0;
+    hipEvent_t pev[NPHASE + 1] = {};
+    bool pev_valid = false;
+    std::vector<hipEvent_t> kev;   // start/stop pairs around trailing updates
+    int kev_used = 0;
+    double kev_flop = 0, kev_ms_done = 0;
+    long long kev_launches_done = 0;
+    double kev_flop_done = 0;
+};
+
+namespace {
+
+HyperScalars scalars(const cugp_gp* g)
+{
+    // covkernel.cpp:65-67 -- exp(2*theta) on the host
+    return HyperScalars{std::exp(g->hp[0] * 2), std::exp(g->hp[1] * 2), std::exp(g->hp[2] * 2)};
+}
+
+int use_device(const cugp_gp* g)
+{
+    HIPCHK(hipSetDevice(g->device));
+    return CUGP_OK;
+}
+
+int ensure(double** p, size_t count)
+{
+    if (*p) return CUGP_OK;
+    HIPCHK(hipMalloc((void**)p, count * sizeof(double)));
+    return CUGP_OK;
+}
+
+int ensure_factor_bufs(cugp_gp* g)
+{
+    const size_t nn = (size_t)g->npad * g->npad;
+    int rc;
+    if ((rc = ensure(&g->dA, nn))) return rc;
+    if ((rc = ensure(&g->dT, nn))) return rc;   // diagonal-block inverses live in T's diagonal tiles
+    if ((rc = ensure(&g->dU, nn))) return rc;
+    return CUGP_OK;
+}
+
+int ensure_inverse_bufs(cugp_gp* g)
+{
+    return ensure(&g->dKinv, (size_t)g->npad * g->npad);
+}
+
+void drain_kernel_events(cugp_gp* g)
+{
+    // fold finished per-launch events into the running sums (events are on g->stream, already synchronised)
+    for (int i = 0; i + 1 < g->kev_used; i += 2) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, g->kev[i], g->kev[i + 1]) == hipSuccess) {
+            g->kev_ms_done += ms;
+            g->kev_launches_done += 1;
+        }
+    }
+    g->kev_flop_done += g->kev_flop;
+    g->kev_flop = 0;
+    g->kev_used = 0;
+}
+
+// blocked right-looking Cholesky of A (lower), diagonal-block inverses into T/U's diagonal tiles
+int enqueue_potrf(cugp_gp* g)
+{
+    hipStream_t s = g->stream;
+    const int nt = g->nt, ld = g->npad;
+    for (int kb = 0; kb < nt; kb++) {
+        launch_potf2(g->dA, ld, kb, g->d16, g->dlogdet, s);
+        launch_trtri_diag(g->dA, ld, kb, 1, g->d16, g->dT, g->dU, s);
+        if (kb + 1 < nt) {
+            launch_trsm_panel(g->dA, g->dT, ld, kb, nt, s);
+            const bool ev = g->prof >= 2 && g->kev_used + 2 <= (int)g->kev.size();
+            if (ev) HIPCHK(hipEventRecord(g->kev[g->kev_used], s));
+            launch_syrk_trail(g->dA, ld, kb, nt, s);
+            if (ev) {
+                HIPCHK(hipEventRecord(g->kev[g->kev_used + 1], s));
+                g->kev_used += 2;
+                const double m = (double)(nt - kb - 1) * TILE;
+                g->kev_flop += m * m * TILE;            // lower triangle only: m^2 * nb (mul+add)
+            }
+        }
+    }
+    HIPCHK(hipGetLastError());
+    return CUGP_OK;
+}
+
+int enqueue_trtri(cugp_gp* g)
+{
+    for (int s = 1; s < g->nt; s *= 2) {
+        launch_trtri_level(g->dA, g->dT, g->dU, g->npad, g->nt, s, 1, g->stream);
+        launch_trtri_level(g->dA, g->dT, g->dU, g->npad, g->nt, s, 2, g->stream);
+    }
+    HIPCHK(hipGetLastError());
+    return CUGP_OK;
+}
+
+int phase_mark(cugp_gp* g, int i)
+{
+    if (g->prof >= 1) HIPCHK(hipEventRecord(g->pev[i], g->stream));
+    return CUGP_OK;
+}
+
+// K build + factorisation (+ inverse quantities, traces when want_grad); results land in dout
+int enqueue_eval(cugp_gp* g, bool want_grad)
+{
+    int rc;
+    if (!g->have_data) return fail(CUGP_ERR_INVALID, "no training data set (cugp_set_data)");
+    if ((rc = use_device(g))) return rc;
+    if ((rc = ensure_factor_bufs(g))) return rc;
+    if (want_grad && (rc = ensure_inverse_bufs(g))) return rc;
+    const HyperScalars h = scalars(g);
+    hipStream_t s = g->stream;
+    g->factor_valid = g->inverse_valid = false;
+
+    if ((rc = phase_mark(g, 0))) return rc;
+    launch_kbuild(g->dX, g->n, g->d, g->npad, h, g->dA, false, s);
+    if ((rc = phase_mark(g, 1))) return rc;
+    if ((rc = enqueue_potrf(g))) return rc;
+    if ((rc = phase_mark(g, 2))) return rc;
+    if (want_grad) {
+        if ((rc = enqueue_trtri(g))) return rc;
+        if ((rc = phase_mark(g, 3))) return rc;
+        launch_lauum(g->dU, g->dKinv, g->npad, g->nt, s);
+        if ((rc = phase_mark(g, 4))) return rc;
+        launch_trmv_lower(g->dT, g->npad, g->npad, g->dy, g->dz, s);        // z = L^-1 y
+        launch_trmv_upper(g->dU, g->npad, g->npad, g->dz, g->dalpha, s);    // alpha = L^-T z
+        launch_trace(g->dX, g->n, g->d, g->npad, h, g->dKinv, g->dalpha, g->dpart, s);
+        launch_finalize(g->dz, g->npad, g->n, g->dlogdet, g->nt, g->dpart, g->nblocks_trace, h, g->dout, s);
+    } else {
+        if ((rc = phase_mark(g, 3))) return rc;
+        if ((rc = phase_mark(g, 4))) return rc;
+        HIPCHK(hipMemcpyAsync(g->dw, g->dy, (size_t)g->npad * sizeof(double), hipMemcpyDeviceToDevice, s));
+        launch_trsv_lower(g->dA, g->dT, g->npad, g->nt, g->dw, g->dz, s);   // L z = y
+        launch_finalize(g->dz, g->npad, g->n, g->dlogdet, g->nt, nullptr, 0, h, g->dout, s);
+    }
+    if ((rc = phase_mark(g, 5))) return rc;
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(g->hout, g->dout, 6 * sizeof(double), hipMemcpyDeviceToHost, s));
+    g->pending = true;
+    g->pending_grad = want_grad;
+    g->pev_valid = g->prof >= 1;
+    return CUGP_OK;
+}
+
+int fetch_eval(cugp_gp* g)
+{
+    if (!g->pending) return CUGP_OK;
+    int rc;
+    if ((rc = use_device(g))) return rc;
+    HIPCHK(hipStreamSynchronize(g->stream));
+    g->pending = false;
+    g->last_ll = g->hout[0];
+    g->last_quad = g->hout[4];
+    g->last_logdet = g->hout[5];
+    g->factor_valid = true;
+    if (g->pending_grad) {
+        for (int i = 0; i < 3; i++) g->last_g[i] = g->hout[1 + i];
+        g->inverse_valid = true;
+    }
+    if (g->prof >= 2) drain_kernel_events(g);
+    return CUGP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int cugp_version(void) { return 100; }
+
+const char* cugp_last_error(void) { return g_err.c_str(); }
+
+int cugp_device_count(int* count)
+{
+    if (!count) return CUGP_ERR_INVALID;
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *count = 0; return fail(CUGP_ERR_NODEVICE, "hipGetDeviceCount", e); }
+    *count = c;
+    return CUGP_OK;
+}
+
+int cugp_create(int n, int d, int device, cugp_gp** out)
+{
+    if (!out || n <= 0 || d <= 0) return fail(CUGP_ERR_INVALID, "cugp_create: n, d must be positive");
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0)
+        return fail(CUGP_ERR_NODEVICE, "no HIP device visible (libcugp has no CPU fallback)");
+    if (device < 0 || device >= cnt) return fail(CUGP_ERR_INVALID, "cugp_create: device index out of range");
+    cugp_gp* g = new (std::nothrow) cugp_gp;
+    if (!g) return fail(CUGP_ERR_NOMEM, "host allocation");
+    g->n = n; g->d = d; g->device = device;
+    g->nt = (n + TILE - 1) / TILE;
+    g->npad = g->nt * TILE;
+    g->nblocks_trace = trace_num_blocks(g->npad);
+    *out = nullptr;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void**)&g->dX, (size_t)n * d * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&g->dy, (size_t)g->npad * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&g->dz, (size_t)g->npad * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&g->dalpha, (size_t)g->npad * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&g->dw, (size_t)g->npad * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&g->d16, (size_t)g->nt * 8 * 256 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&g->dlogdet, (size_t)g->nt * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&g->dpart, (size_t)g->nblocks_trace * 3 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&g->dout, 8 * sizeof(double));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&g->hout, 8 * sizeof(double), hipHostMallocDefault);
+    for (int i = 0; i <= NPHASE && e == hipSuccess; i++) e = hipEventCreate(&g->pev[i]);
+    if (e != hipSuccess) {
+        int code = fail(e == hipErrorOutOfMemory ? CUGP_ERR_NOMEM : CUGP_ERR_DEVICE, "cugp_create", e);
+        cugp_destroy(g);
+        return code;
+    }
+    *out = g;
+    return CUGP_OK;
+}
+
+int cugp_destroy(cugp_gp* g)
+{
+    if (!g) return CUGP_OK;
+    (void)hipSetDevice(g->device);
+    if (g->stream) (void)hipStreamSynchronize(g->stream);
+    double* bufs[] = {g->dX, g->dy, g->dA, g->dT, g->dU, g->dKinv, g->dz, g->dalpha, g->dw, g->d16, g->dlogdet,
+                      g->dpart, g->dout};
+    for (double* p : bufs)
+        if (p) (void)hipFree(p);
+    if (g->hout) (void)hipHostFree(g->hout);
+    for (int i = 0; i <= NPHASE; i++)
+        if (g->pev[i]) (void)hipEventDestroy(g->pev[i]);
+    for (hipEvent_t e : g->kev) (void)hipEventDestroy(e);
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+    delete g;
+    return CUGP_OK;
+}
+
+int cugp_dims(const cugp_gp* g, int* n, int* d, int* npad)
+{
+    if (!g) return CUGP_ERR_INVALID;
+    if (n) *n = g->n;
+    if (d) *d = g->d;
+    if (npad) *npad = g->npad;
+    return CUGP_OK;
+}
+
+static int set_data_common(cugp_gp* g, const double* X, const double* y, hipMemcpyKind kind)
+{
+    if (!g || !X || !y) return fail(CUGP_ERR_INVALID, "cugp_set_data: null argument");
+    int rc;
+    if ((rc = use_device(g))) return rc;
+    if ((rc = fetch_eval(g))) return rc;
+    HIPCHK(hipMemcpyAsync(g->dX, X, (size_t)g->n * g->d * sizeof(double), kind, g->stream));
+    HIPCHK(hipMemsetAsync(g->dy, 0, (size_t)g->npad * sizeof(double), g->stream));
+    HIPCHK(hipMemcpyAsync(g->dy, y, (size_t)g->n * sizeof(double), kind, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
+    g->have_data = true;
+    g->factor_valid = g->inverse_valid = false;
+    return CUGP_OK;
+}
+
+int cugp_set_data(cugp_gp* g, const double* X, const double* y) { return set_data_common(g, X, y, hipMemcpyHostToDevice); }
+
+int cugp_set_data_device(cugp_gp* g, const double* dX, const double* dy)
+{
+    return set_data_common(g, dX, dy, hipMemcpyDeviceToDevice);
+}
+
+int cugp_set_loghyper(cugp_gp* g, const double hp[3])
+{
+    if (!g || !hp) return CUGP_ERR_INVALID;
+    int rc;
+    if ((rc = fetch_eval(g))) return rc;
+    if (hp[0] != g->hp[0] || hp[1] != g->hp[1] || hp[2] != g->hp[2] || std::isnan(hp[0] + hp[1] + hp[2]))
+        g->factor_valid = g->inverse_valid = false;
+    for (int i = 0; i < 3; i++) g->hp[i] = hp[i];
+    return CUGP_OK;
+}
+
+int cugp_get_loghyper(const cugp_gp* g, double hp[3])
+{
+    if (!g || !hp) return CUGP_ERR_INVALID;
+    for (int i = 0; i < 3; i++) hp[i] = g->hp[i];
+    return CUGP_OK;
+}
+
+int cugp_loglik_grad_enqueue(cugp_gp* g, int want_grad)
+{
+    if (!g) return CUGP_ERR_INVALID;
+    int rc;
+    if ((rc = fetch_eval(g))) return rc;
+    return enqueue_eval(g, want_grad != 0);
+}
+
+int cugp_loglik_grad_fetch(cugp_gp* g, double* ll, double gr[3])
+{
+    if (!g) return CUGP_ERR_INVALID;
+    int rc;
+    if ((rc = fetch_eval(g))) return rc;
+    if (ll) *ll = g->last_ll;
+    if (gr)
+        for (int i = 0; i < 3; i++) gr[i] = g->last_g[i];
+    return CUGP_OK;
+}
+
+int cugp_loglik(cugp_gp* g, double* ll)
+{
+    if (!g || !ll) return CUGP_ERR_INVALID;
+    int rc;
+    if ((rc = fetch_eval(g))) return rc;
+    if (!g->factor_valid) {
+        if ((rc = enqueue_eval(g, false))) return rc;
+        if ((rc = fetch_eval(g))) return rc;
+    }
+    *ll = g->last_ll;
+    return CUGP_OK;
+}
+
+int cugp_loglik_grad(cugp_gp* g, double* ll, double gr[3])
+{
+    if (!g) return CUGP_ERR_INVALID;
+    int rc;
+    if ((rc = fetch_eval(g))) return rc;
+    if (!g->inverse_valid) {
+        if ((rc = enqueue_eval(g, true))) return rc;
+        if ((rc = fetch_eval(g))) return rc;
+    }
+    if (ll) *ll = g->last_ll;
+    if (gr)
+        for (int i = 0; i < 3; i++) gr[i] = g->last_g[i];
+    return CUGP_OK;
+}
+
+int cugp_grad(cugp_gp* g, double gr[3]) { return cugp_loglik_grad(g, nullptr, gr); }
+
+int cugp_last_quad_logdet(const cugp_gp* g, double* quad, double* logdet)
+{
+    if (!g || !g->factor_valid) return fail(CUGP_ERR_INVALID, "no evaluation available");
+    if (quad) *quad = g->last_quad;
+    if (logdet) *logdet = g->last_logdet;
+    return CUGP_OK;
+}
+
+// ---------------------------------------------------------------- prediction
+int cugp_nlpp(const double* actual, const double* mean, const double* var, int nt, double* nlpp)
+{
+    if (!actual || !mean || !var || !nlpp || nt <= 0) return CUGP_ERR_INVALID;
+    double acc = 0.0;   // covkernel.cpp:649-659, 2*pi truncated to 6.283185
+    for (int i = 0; i < nt; i++)
+        acc += 0.5 * std::log(6.283185 * var[i]) + std::pow((mean[i] - actual[i]), 2) / (2 * var[i]);
+    *nlpp = acc / nt;
+    return CUGP_OK;
+}
+
+static int predict_device(cugp_gp* g, const double* Xt, int nt, double** dmean_out, double** dvar_out,
+                          std::vector<double*>& to_free)
+{
+    int rc;
+    if ((rc = cugp_loglik_grad(g, nullptr, nullptr))) return rc;     // factor, T, alpha for the current hp
+    const int ntpad = ((nt + TILE - 1) / TILE) * TILE;
+    const HyperScalars h = scalars(g);
+    double *dXt = nullptr, *dKs = nullptr, *dW = nullptr, *dm = nullptr, *dv = nullptr;
+    HIPCHK(hipMalloc((void**)&dXt, (size_t)nt * g->d * sizeof(double))); to_free.push_back(dXt);
+    HIPCHK(hipMalloc((void**)&dKs, (size_t)ntpad * g->npad * sizeof(double))); to_free.push_back(dKs);
+    HIPCHK(hipMalloc((void**)&dW, (size_t)ntpad * g->npad * sizeof(double))); to_free.push_back(dW);
+    HIPCHK(hipMalloc((void**)&dm, (size_t)nt * sizeof(double))); to_free.push_back(dm);
+    HIPCHK(hipMalloc((void**)&dv, (size_t)nt * sizeof(double))); to_free.push_back(dv);
+    HIPCHK(hipMemcpyAsync(dXt, Xt, (size_t)nt * g->d * sizeof(double), hipMemcpyHostToDevice, g->stream));
+    launch_kcross(g->dX, g->n, g->d, g->npad, dXt, nt, ntpad, h, dKs, g->stream);
+    launch_predict_gemm(dKs, g->dT, dW, g->npad, ntpad / TILE, g->nt, g->stream);
+    launch_predict_finish(dKs, dW, g->dalpha, g->n, g->npad, nt, h, dm, dv, g->stream);
+    HIPCHK(hipGetLastError());
+    *dmean_out = dm;
+    *dvar_out = dv;
+    return CUGP_OK;
+}
+
+int cugp_predict(cugp_gp* g, const double* Xt, int nt, double* mean, double* var)
+{
+    if (!g || !Xt || !mean || !var || nt <= 0) return fail(CUGP_ERR_INVALID, "cugp_predict: bad argument");
+    std::vector<double*> tmp;
+    double *dm = nullptr, *dv = nullptr;
+    int rc = predict_device(g, Xt, nt, &dm, &dv, tmp);
+    if (rc == CUGP_OK) {
+        hipError_t e = hipMemcpyAsync(mean, dm, (size_t)nt * sizeof(double), hipMemcpyDeviceToHost, g->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(var, dv, (size_t)nt * sizeof(double), hipMemcpyDeviceToHost, g->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+        if (e != hipSuccess) rc = fail(CUGP_ERR_DEVICE, "cugp_predict copy", e);
+    }
+    (void)hipStreamSynchronize(g->stream);
+    for (double* p : tmp) (void)hipFree(p);
+    return rc;
+}
+
+// ---------------------------------------------------------------- intermediates
+int cugp_compute_K_train(cugp_gp* g, double* K)
+{
+    if (!g || !K) return CUGP_ERR_INVALID;
+    if (!g->have_data) return fail(CUGP_ERR_INVALID, "no training data set");
+    int rc;
+    if ((rc = use_device(g))) return rc;
+    if ((rc = fetch_eval(g))) return rc;
+    if ((rc = ensure(&g->dA, (size_t)g->npad * g->npad))) return rc;
+    g->factor_valid = g->inverse_valid = false;
+    launch_kbuild(g->dX, g->n, g->d, g->npad, scalars(g), g->dA, true, g->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy2DAsync(K, (size_t)g->n * sizeof(double), g->dA, (size_t)g->npad * sizeof(double),
+                            (size_t)g->n * sizeof(double), g->n, hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
+    return CUGP_OK;
+}
+
+int cugp_compute_k_test(cugp_gp* g, const double* Xt, int nt, double* Ks)
+{
+    if (!g || !Xt || !Ks || nt <= 0) return CUGP_ERR_INVALID;
+    if (!g->have_data) return fail(CUGP_ERR_INVALID, "no training data set");
+    int rc;
+    if ((rc = use_device(g))) return rc;
+    const int ntpad = ((nt + TILE - 1) / TILE) * TILE;
+    double *dXt = nullptr, *dKs = nullptr;
+    HIPCHK(hipMalloc((void**)&dXt, (size_t)nt * g->d * sizeof(double)));
+    hipError_t e = hipMalloc((void**)&dKs, (size_t)ntpad * g->npad * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpyAsync(dXt, Xt, (size_t)nt * g->d * sizeof(double), hipMemcpyHostToDevice, g->stream);
+    if (e == hipSuccess) {
+        launch_kcross(g->dX, g->n, g->d, g->npad, dXt, nt, ntpad, scalars(g), dKs, g->stream);
+        e = hipMemcpy2DAsync(Ks, (size_t)g->n * sizeof(double), dKs, (size_t)g->npad * sizeof(double),
+                             (size_t)g->n * sizeof(double), nt, hipMemcpyDeviceToHost, g->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+    (void)hipFree(dXt);
+    if (dKs) (void)hipFree(dKs);
+    if (e != hipSuccess) return fail(CUGP_ERR_DEVICE, "cugp_compute_k_test", e);
+    return CUGP_OK;
+}
+
+static int copy_square(cugp_gp* g, const double* dsrc, double* dst)
+{
+    HIPCHK(hipMemcpy2DAsync(dst, (size_t)g->n * sizeof(double), dsrc, (size_t)g->npad * sizeof(double),
+                            (size_t)g->n * sizeof(double), g->n, hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
+    return CUGP_OK;
+}
+
+int cugp_get_cholesky(cugp_gp* g, double* L)
+{
+    if (!g || !L) return CUGP_ERR_INVALID;
+    int rc;
+    if ((rc = fetch_eval(g))) return rc;
+    if (!g->factor_valid) return fail(CUGP_ERR_INVALID, "cugp_get_cholesky: evaluate the likelihood first");
+    if ((rc = use_device(g))) return rc;
+    if ((rc = copy_square(g, g->dA, L))) return rc;
+    for (int i = 0; i < g->n; i++)                       // matrixops.cpp:100-107: strict upper zeroed
+        for (int j = i + 1; j < g->n; j++) L[(size_t)i * g->n + j] = 0.0;
+    return CUGP_OK;
+}
+
+int cugp_get_K_inverse(cugp_gp* g, double* Kinv)
+{
+    if (!g || !Kinv) return CUGP_ERR_INVALID;
+    int rc;
+    if ((rc = fetch_eval(g))) return rc;
+    if (!g->inverse_valid) return fail(CUGP_ERR_INVALID, "cugp_get_K_inverse: evaluate the gradient first");
+    if ((rc = use_device(g))) return rc;
+    if ((rc = copy_square(g, g->dKinv, Kinv))) return rc;
+    for (int i = 0; i < g->n; i++)
+        for (int j = i + 1; j < g->n; j++) Kinv[(size_t)i * g->n + j] = Kinv[(size_t)j * g->n + i];
+    return CUGP_OK;
+}
+
+int cugp_get_alpha(cugp_gp* g, double* alpha)
+{
+    if (!g || !alpha) return CUGP_ERR_INVALID;
+    int rc;
+    if ((rc = fetch_eval(g))) return rc;
+    if (!g->inverse_valid) return fail(CUGP_ERR_INVALID, "cugp_get_alpha: evaluate the gradient first");
+    if ((rc = use_device(g))) return rc;
+    HIPCHK(hipMemcpyAsync(alpha, g->dalpha, (size_t)g->n * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
+    return CUGP_OK;
+}
+
+// ---------------------------------------------------------------- stand-alone LA
+namespace {
+
+// a handle whose A holds a caller matrix (identity padded) instead of a kernel build
+int la_handle(int n, const double* K, const double* y, int device, cugp_gp** out)
+{
+    int rc = cugp_create(n, 1, device, out);
+    if (rc) return rc;
+    cugp_gp* g = *out;
+    if ((rc = ensure_factor_bufs(g)) || (rc = ensure_inverse_bufs(g))) { cugp_destroy(g); return rc; }
+    std::vector<double> pad((size_t)g->npad * g->npad, 0.0);
+    for (int i = 0; i < g->npad; i++) {
+        if (i < n) memcpy(&pad[(size_t)i * g->npad], K + (size_t)i * n, (size_t)n * sizeof(double));
+        else pad[(size_t)i * g->npad + i] = 1.0;
+    }
+    hipError_t e = hipMemcpy(g->dA, pad.data(), pad.size() * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(g->dy, 0, (size_t)g->npad * sizeof(double));
+    if (e == hipSuccess && y) e = hipMemcpy(g->dy, y, (size_t)n * sizeof(double), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { cugp_destroy(g); return fail(CUGP_ERR_DEVICE, "la upload", e); }
+    return CUGP_OK;
+}
+
+int la_factor_inverse(cugp_gp* g, bool inverse)
+{
+    int rc;
+    if ((rc = enqueue_potrf(g))) return rc;
+    if (inverse) {
+        if ((rc = enqueue_trtri(g))) return rc;
+        launch_lauum(g->dU, g->dKinv, g->npad, g->nt, g->stream);
+    }
+    HIPCHK(hipStreamSynchronize(g->stream));
+    g->factor_valid = true;
+    g->inverse_valid = inverse;
+    return CUGP_OK;
+}
+
+}  // namespace
+
+int cugp_potrf(int n, const double* K, double* L, int device)
+{
+    if (n <= 0 || !K || !L) return CUGP_ERR_INVALID;
+    cugp_gp* g = nullptr;
+    int rc = la_handle(n, K, nullptr, device, &g);
+    if (rc) return rc;
+    if (!(rc = la_factor_inverse(g, false))) rc = cugp_get_cholesky(g, L);
+    cugp_destroy(g);
+    return rc;
+}
+
+int cugp_potri(int n, const double* K, double* Kinv, int device)
+{
+    if (n <= 0 || !K || !Kinv) return CUGP_ERR_INVALID;
+    cugp_gp* g = nullptr;
+    int rc = la_handle(n, K, nullptr, device, &g);
+    if (rc) return rc;
+    if (!(rc = la_factor_inverse(g, true))) rc = cugp_get_K_inverse(g, Kinv);
+    cugp_destroy(g);
+    return rc;
+}
+
+static int la_solve(int n, const double* K, const double* y, double* x, double* quad, double* logdet, int device)
+{
+    cugp_gp* g = nullptr;
+    int rc = la_handle(n, K, y, device, &g);
+    if (rc) return rc;
+    if (!(rc = enqueue_potrf(g)) && !(rc = enqueue_trtri(g))) {
+        launch_trmv_lower(g->dT, g->npad, g->npad, g->dy, g->dz, g->stream);
+        launch_trmv_upper(g->dU, g->npad, g->npad, g->dz, g->dalpha, g->stream);
+        launch_finalize(g->dz, g->npad, g->n, g->dlogdet, g->nt, nullptr, 0, scalars(g), g->dout, g->stream);
+        hipError_t e = hipMemcpyAsync(g->hout, g->dout, 6 * sizeof(double), hipMemcpyDeviceToHost, g->stream);
+        if (e == hipSuccess && x)
+            e = hipMemcpyAsync(x, g->dalpha, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, g->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
+        if (e != hipSuccess) rc = fail(CUGP_ERR_DEVICE, "la_solve", e);
+        else {
+            if (quad) *quad = g->hout[4];
+            if (logdet) *logdet = g->hout[5];
+        }
+    }
+    cugp_destroy(g);
+    return rc;
+}
+
+int cugp_chol_and_det(int n, const double* K, const double* y, double* quad, double* logdet, int device)
+{
+    if (n <= 0 || !K || !y || !quad || !logdet) return CUGP_ERR_INVALID;
+    return la_solve(n, K, y, nullptr, quad, logdet, device);
+}
+
+int cugp_potrs_vec(int n, const double* K, const double* y, double* x, int device)
+{
+    if (n <= 0 || !K || !y || !x) return CUGP_ERR_INVALID;
+    return la_solve(n, K, y, x, nullptr, nullptr, device);
+}
+
+// ---------------------------------------------------------------- timing
+int cugp_set_profiling(cugp_gp* g, int level)
+{
+    if (!g) return CUGP_ERR_INVALID;
+    int rc;
+    if ((rc = use_device(g))) return rc;
+    if ((rc = fetch_eval(g))) return rc;
+    g->prof = level;
+    if (level >= 2 && g->kev.empty()) {
+        g->kev.resize(MAX_KEV);
+        for (auto& e : g->kev) HIPCHK(hipEventCreate(&e));
+    }
+    return CUGP_OK;
+}
+
+int cugp_get_phase_ms(cugp_gp* g, double ms[6])
+{
+    if (!g || !ms) return CUGP_ERR_INVALID;
+    int rc;
+    if ((rc = fetch_eval(g))) return rc;
+    if (!g->pev_valid) return fail(CUGP_ERR_INVALID, "profiling was off for the last evaluation");
+    if ((rc = use_device(g))) return rc;
+    for (int i = 0; i < 5; i++) {
+        float t = 0;
+        HIPCHK(hipEventElapsedTime(&t, g->pev[i], g->pev[i + 1]));
+        ms[i] = t;
+    }
+    float t = 0;
+    HIPCHK(hipEventElapsedTime(&t, g->pev[0], g->pev[5]));
+    ms[5] = t;
+    return CUGP_OK;
+}
+
+int cugp_get_kernel_stats(cugp_gp* g, double* sum_ms, long long* launches, double* flop, int reset)
+{
+    if (!g) return CUGP_ERR_INVALID;
+    int rc;
+    if ((rc = fetch_eval(g))) return rc;
+    if (sum_ms) *sum_ms = g->kev_ms_done;
+    if (launches) *launches = g->kev_launches_done;
+    if (flop) *flop = g->kev_flop_done;
+    if (reset) { g->kev_ms_done = 0; g->kev_launches_done = 0; g->kev_flop_done = 0; }
+    return CUGP_OK;
+}
+
+void* cugp_get_stream(cugp_gp* g) { return g ? (void*)g->stream : nullptr; }
+
+// ---------------------------------------------------------------- optimiser glue
+namespace {
+void gp_objective(void* ctx, const double th[3], double* f, double gr[3])
+{
+    cugp_gp* g = (cugp_gp*)ctx;
+    double ll = NAN;
+    cugp_set_loghyper(g, th);
+    if (cugp_loglik_grad(g, &ll, gr) != CUGP_OK) { ll = NAN; gr[0] = gr[1] = gr[2] = NAN; }
+    *f = -1.0 * ll;
+}
+}  // namespace
+
+int cugp_cg_solve(cugp_gp* g, int budget, double* trace, int trace_cap, int* nevals)
+{
+    if (!g) return CUGP_ERR_INVALID;
+    double th[3] = {g->hp[0], g->hp[1], g->hp[2]};
+    int rc = cugp_cg_minimize(gp_objective, g, th, budget, trace, trace_cap, nevals);
+    if (rc) return rc;
+    return cugp_set_loghyper(g, th);       // covkernel.cpp:646
+}
+
+int cugp_rprop_solve(cugp_gp* g, int iters, double* trace, int trace_cap, int* nevals)
+{
+    if (!g) return CUGP_ERR_INVALID;
+    double th[3] = {g->hp[0], g->hp[1], g->hp[2]};
+    int rc = cugp_rprop_minimize(gp_objective, g, th, iters, trace, trace_cap, nevals);
+    if (rc) return rc;
+    return cugp_set_loghyper(g, th);
+}
+
+// ---------------------------------------------------------------- test hooks
+int cugp_test_gemm_nt(int m, int n, int k, const double* A, const double* B, double* C, int device)
+{
+    if (m <= 0 || n <= 0 || k <= 0 || m % TILE || n % TILE || k % 16 || !A || !B || !C)
+        return fail(CUGP_ERR_INVALID, "cugp_test_gemm_nt: m,n multiples of 128 and k of 16");
+    HIPCHK(hipSetDevice(device));
+    double *dA = nullptr, *dB = nullptr, *dC = nullptr;
+    HIPCHK(hipMalloc((void**)&dA, (size_t)m * k * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&dB, (size_t)n * k * sizeof(double)));
+    HIPCHK(hipMalloc((void**)&dC, (size_t)m * n * sizeof(double)));
+    HIPCHK(hipMemcpy(dA, A, (size_t)m * k * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dB, B, (size_t)n * k * sizeof(double), hipMemcpyHostToDevice));
+    launch_test_gemm_nt(dA, dB, dC, m, n, k, nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(C, dC, (size_t)m * n * sizeof(double), hipMemcpyDeviceToHost));
+    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dC);
+    return CUGP_OK;
+}
+
+int cugp_mfma_peak_tflops(int device, double* tflops)
+{
+    if (!tflops) return CUGP_ERR_INVALID;
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    const int blocks = prop.multiProcessorCount * 2;      // 8 waves per CU = 2 per SIMD
+    const int iters = 20000;
+    double* sink = nullptr;
+    HIPCHK(hipMalloc((void**)&sink, (size_t)blocks * 256 * sizeof(double)));
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    launch_mfma_peak(sink, blocks, 2000, nullptr);
+    HIPCHK(hipEventRecord(a, nullptr));
+    launch_mfma_peak(sink, blocks, iters, nullptr);
+    HIPCHK(hipEventRecord(b, nullptr));
+    HIPCHK(hipEventSynchronize(b));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, a, b));
+    const double flop = (double)blocks * 4 /*waves*/ * iters * 8.0 * 2048.0;
+    *tflops = flop / (ms * 1e-3) / 1e12;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipFree(sink);
+    return CUGP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,57 @@
+// kernels.h -- internal launch interface between the C-ABI (cugp_capi.cpp) and
+// the gfx950 kernels (kernels.hip).  Not part of the public boundary.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace cugp {
+
+constexpr int TILE = 128;          // tile edge of every fp64 MFMA product and of the padded leading dimension
+
+struct HyperScalars {              // exp(2*theta) evaluated on the host, as the reference does (covkernel.cpp:65-67)
+    double ell_sq, signal_var, noise_var;
+};
+
+// ---- SE covariance (N1) ----
+// lower 64x64 tiles of K (+ mirror when `full`), padding rows/cols >= n set to identity
+void launch_kbuild(const double* X, int n, int d, int npad, HyperScalars h, double* K, bool full,
+                   hipStream_t s);
+// Ks[t][i] = sf2 * exp(-0.5*|x_i - xt_t|^2 / l^2), row-major nt_pad x npad (pad = 0)   (N12)
+void launch_kcross(const double* X, int n, int d, int npad, const double* Xt, int nt, int ntpad,
+                   HyperScalars h, double* Ks, hipStream_t s);
+
+// ---- blocked right-looking Cholesky (N4) on the lower triangle of A (npad x npad, ld = npad) ----
+void launch_potf2(double* A, int ld, int kb, double* d16, double* logdet_part, hipStream_t s);
+void launch_trtri_diag(const double* A, int ld, int kb, int nblocks, const double* d16, double* T, double* U,
+                       hipStream_t s);
+void launch_trsm_panel(double* A, const double* T, int ld, int kb, int nt, hipStream_t s);
+void launch_syrk_trail(double* A, int ld, int kb, int nt, hipStream_t s);
+
+// ---- triangular inverse by recursive doubling (N7) and K^-1 = U U^T (N8) ----
+void launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, int s, int step, hipStream_t st);
+void launch_lauum(const double* U, double* Kinv, int ld, int nt, hipStream_t s);
+
+// ---- prediction products ----
+// W[t][i] = sum_{k<=i} Ks[t][k] T[i][k]   (nt_pad x npad, row-major)
+void launch_predict_gemm(const double* Ks, const double* T, double* W, int ld, int ntt, int nt, hipStream_t s);
+void launch_predict_finish(const double* Ks, const double* W, const double* alpha, int n, int npad, int ntest,
+                           HyperScalars h, double* mean, double* var, hipStream_t s);
+
+// ---- vector kernels ----
+void launch_trmv_lower(const double* T, int ld, int npad, const double* x, double* z, hipStream_t s);  // z = T x
+void launch_trmv_upper(const double* U, int ld, int npad, const double* x, double* a, hipStream_t s);  // a = U x
+void launch_trsv_lower(const double* A, const double* T, int ld, int nt, const double* y, double* z,
+                       hipStream_t s);                                                                 // L z = y
+// gradient traces (N10+N11 fused): partial sums per block into part[3*nblocks]
+int trace_num_blocks(int npad);
+void launch_trace(const double* X, int n, int d, int npad, HyperScalars h, const double* Kinv,
+                  const double* alpha, double* part, hipStream_t s);
+// out[0..3] = LL, g0, g1, g2  (LL only when part == nullptr)
+void launch_finalize(const double* z, int npad, int n, const double* logdet_part, int nt, const double* part,
+                     int nblocks, HyperScalars h, double* out, hipStream_t s);
+
+// test hook: C[m x n] = A[m x k] * B[n x k]^T on the MFMA tile path (all multiples of 128 / 16)
+void launch_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, int k, hipStream_t s);
+// peak probe: `iters` dependent-free fp64 MFMAs per wave; returns nothing, timed by the caller
+void launch_mfma_peak(double* sink, int blocks, int iters, hipStream_t s);
+
+}  // namespace cugp

@@ -1,0 +1,875 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for the GP hot path.
+//
+// Path (reference file:line each kernel replaces):
+//   k_build        SE+noise covariance          cpp_serial_gp/covkernel.cpp:64-102, cuda_scalingdist/cuda_gp.cu:232-281
+//   potf2 / trsm / syrk   blocked right-looking Cholesky   common/matrixops.cpp:68-108,
+//                  cpp_matrixalgebra/blocked_cholesky.cpp:221-262, cuda_src/cuda_gp.cu:1237-1308
+//   trtri_*        L^-1 by recursive doubling   common/matrixops.cpp:330-340, cuda_src/cuda_gp.cu:1854-1915 (TMI)
+//   lauum          K^-1 = L^-T L^-1             common/matrixops.cpp:383-435, cuda_src/cuda_gp.cu:119-136
+//   trmv / trace / finalize   alpha, y'K^-1 y, log|K|, gradient traces   covkernel.cpp:118-129,162-263
+//   kcross / predict_*        predictive mean / variance                 covkernel.cpp:105-116,277-323
+//
+// Everything dense runs through ONE fp64 MFMA tile product (v_mfma_f64_16x16x4_f64):
+//   C[128x128] = sum_k A[i][k] * B[j][k]   ("NT": both operands row-major with k contiguous)
+// 4 waves per workgroup in a 2x2 grid, 64x64 per wave = 4x4 MFMA tiles (64 fp64 accumulators
+// per lane), K staged 16 deep through LDS, double-buffered, global loads for stage t+1 in
+// flight while stage t is multiplied.  LDS image: [k-pair plane][row rotated by plane][2 doubles]
+// -- fragment reads are 256 contiguous bytes per 32 lanes (conflict-free ds_read_b64), staging
+// writes (8 lanes = 8 planes of one row) land on 8 different 16-B slots (conflict-free b128).
+//
+// Matrices are npad x npad row-major with npad = ceil(n/128)*128; the padding of K is the
+// identity, so every kernel works on whole tiles and the factor, inverse, log-determinant and
+// traces of the leading n x n block are unchanged.
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+namespace cugp {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------------------------------
+// fp64 MFMA tile product
+// ------------------------------------------------------------------------------------------
+constexpr int BK = 16;                       // k depth per LDS stage
+constexpr int PLANE = TILE * 16;             // bytes per k-pair plane (128 rows x 2 doubles)
+constexpr int OPER = (BK / 2) * PLANE;       // bytes per operand per stage  (16 KiB)
+constexpr int STAGE = 2 * OPER;              // A + B
+constexpr int GEMM_LDS = 2 * STAGE;          // double buffered: 64 KiB
+
+__device__ __forceinline__ int lds_slot(int row, int plane) { return ((row + plane) & (TILE - 1)) * 16; }
+
+// acc[m][n] += A(i0.., kbeg..kend) * B(j0.., kbeg..kend)^T ; Ag -> A[i0][0], Bg -> B[j0][0];
+// kbeg, kend multiples of BK.  All 256 threads must call (barriers inside).
+__device__ __forceinline__ void tile_nt(const double* __restrict__ Ag, int lda, const double* __restrict__ Bg,
+                                        int ldb, int kbeg, int kend, d4 (&acc)[4][4], char* smem)
+{
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+
+    // staging map: 4 chunks of 16 B per operand per thread; 8 consecutive lanes cover one row's 128 B
+    const int srow = t >> 3, skp = t & 7;                 // + 32 rows per q
+    const double* ag = Ag + (size_t)srow * lda + 2 * skp;
+    const double* bg = Bg + (size_t)srow * ldb + 2 * skp;
+    d2 ra[4], rb[4];
+
+    const int nk = (kend - kbeg) / BK;
+    if (nk <= 0) return;
+
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        ra[q] = *(const d2*)(ag + (size_t)(32 * q) * lda + kbeg);
+        rb[q] = *(const d2*)(bg + (size_t)(32 * q) * ldb + kbeg);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        int row = srow + 32 * q;
+        *(d2*)(smem + skp * PLANE + lds_slot(row, skp)) = ra[q];
+        *(d2*)(smem + OPER + skp * PLANE + lds_slot(row, skp)) = rb[q];
+    }
+    __syncthreads();
+
+    const int fr = lane & 15, fk = lane >> 4;            // fragment row within 16, k within 4
+    const int fhi = fk >> 1, flo = (fk & 1) * 8;
+
+    for (int kt = 0; kt < nk; kt++) {
+        char* cur = smem + (kt & 1) * STAGE;
+        char* nxt = smem + ((kt + 1) & 1) * STAGE;
+        const bool more = (kt + 1 < nk);
+        if (more) {
+            const int k = kbeg + (kt + 1) * BK;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                ra[q] = *(const d2*)(ag + (size_t)(32 * q) * lda + k);
+                rb[q] = *(const d2*)(bg + (size_t)(32 * q) * ldb + k);
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 4; kk++) {
+            const int p = kk * 2 + fhi;
+            double a[4], b[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                a[m] = *(const double*)(cur + p * PLANE + lds_slot(wr * 64 + m * 16 + fr, p) + flo);
+                b[m] = *(const double*)(cur + OPER + p * PLANE + lds_slot(wc * 64 + m * 16 + fr, p) + flo);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+#pragma unroll
+                for (int n = 0; n < 4; n++)
+                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+        }
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                int row = srow + 32 * q;
+                *(d2*)(nxt + skp * PLANE + lds_slot(row, skp)) = ra[q];
+                *(d2*)(nxt + OPER + skp * PLANE + lds_slot(row, skp)) = rb[q];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void acc_zero(d4 (&acc)[4][4])
+{
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int n = 0; n < 4; n++) acc[m][n] = (d4){0.0, 0.0, 0.0, 0.0};
+}
+
+// accumulator element (m,n,r) of this lane is C[row][col] with (f64 16x16x4 C/D map:
+// col = lane&15, row = (lane>>4) + 4*r inside each 16x16 tile)
+#define ACC_ROW(m, r) (wr * 64 + (m) * 16 + (lane >> 4) + 4 * (r))
+#define ACC_COL(n) (wc * 64 + (n) * 16 + (lane & 15))
+
+// C = alpha*acc + beta*C
+__device__ __forceinline__ void tile_store(double* __restrict__ C, int ldc, const d4 (&acc)[4][4], double alpha,
+                                           double beta)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int n = 0; n < 4; n++) {
+                double* p = C + (size_t)ACC_ROW(m, r) * ldc + ACC_COL(n);
+                double v = alpha * acc[m][n][r];
+                if (beta != 0.0) v += beta * (*p);
+                *p = v;
+            }
+}
+
+// Ct[col][row] = alpha*acc  (transposed store)
+__device__ __forceinline__ void tile_store_t(double* __restrict__ Ct, int ldc, const d4 (&acc)[4][4], double alpha)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int n = 0; n < 4; n++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                Ct[(size_t)ACC_COL(n) * ldc + ACC_ROW(m, r)] = alpha * acc[m][n][r];
+}
+
+// lower-triangular tile index: idx -> (ti >= tj)
+__device__ __forceinline__ void tri_index(int idx, int& ti, int& tj)
+{
+    int r = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
+    while ((r + 1) * (r + 2) / 2 <= idx) r++;
+    while (r * (r + 1) / 2 > idx) r--;
+    ti = r;
+    tj = idx - r * (r + 1) / 2;
+}
+
+// ---- Cholesky panel: L21 = A21 * T11^T (T11 = inverse of the diagonal factor block), in place ----
+__global__ __launch_bounds__(256, 2) void k_trsm_panel(double* __restrict__ A, const double* __restrict__ T,
+                                                       int ld, int kb)
+{
+    __shared__ __attribute__((aligned(16))) char smem[GEMM_LDS];
+    const int k0 = kb * TILE;
+    const int i0 = (kb + 1 + blockIdx.x) * TILE;
+    d4 acc[4][4];
+    acc_zero(acc);
+    // whole 128-deep k range is read into LDS before the first store, so in place is safe
+    tile_nt(A + (size_t)i0 * ld + k0, ld, T + (size_t)k0 * ld + k0, ld, 0, TILE, acc, smem);
+    tile_store(A + (size_t)i0 * ld + k0, ld, acc, 1.0, 0.0);
+}
+
+// ---- Cholesky trailing update: A22(lower tiles) -= L21 * L21^T ----
+__global__ __launch_bounds__(256, 2) void k_syrk_trail(double* __restrict__ A, int ld, int kb)
+{
+    __shared__ __attribute__((aligned(16))) char smem[GEMM_LDS];
+    int ti, tj;
+    tri_index(blockIdx.x, ti, tj);
+    const int k0 = kb * TILE;
+    const int i0 = (kb + 1 + ti) * TILE, j0 = (kb + 1 + tj) * TILE;
+    d4 acc[4][4];
+    acc_zero(acc);
+    tile_nt(A + (size_t)i0 * ld + k0, ld, A + (size_t)j0 * ld + k0, ld, 0, TILE, acc, smem);
+    tile_store(A + (size_t)i0 * ld + j0, ld, acc, -1.0, 1.0);
+}
+
+// ---- K^-1 (lower tiles, diagonal tiles complete) = U * U^T, U = L^-T upper ----
+__global__ __launch_bounds__(256, 2) void k_lauum(const double* __restrict__ U, double* __restrict__ Kinv, int ld,
+                                                  int nt)
+{
+    __shared__ __attribute__((aligned(16))) char smem[GEMM_LDS];
+    int ti, tj;
+    tri_index(blockIdx.x, ti, tj);       // ascending ti = longest k ranges first
+    d4 acc[4][4];
+    acc_zero(acc);
+    tile_nt(U + (size_t)ti * TILE * ld, ld, U + (size_t)tj * TILE * ld, ld, ti * TILE, nt * TILE, acc, smem);
+    tile_store(Kinv + (size_t)ti * TILE * ld + tj * TILE, ld, acc, 1.0, 0.0);
+}
+
+// ---- recursive-doubling inverse, one level.  Blocks of s tiles: [A 0; C B]^-1 = [TA 0; -TB C TA, TB].
+// step 1: Wt(tj in A, ti in B) = sum_{k in A, k >= tj} U[tj][k] * L[ti][k]   -> scratch in T's upper tiles
+// step 2: T(ti in B, tj in A) = -sum_{k in B, k <= ti} T[ti][k] * Wt[tj][k]   and U(tj,ti) = transpose
+__global__ __launch_bounds__(256, 2) void k_trtri_level(const double* __restrict__ L, double* __restrict__ T,
+                                                        double* __restrict__ U, int ld, int nt, int s, int step)
+{
+    __shared__ __attribute__((aligned(16))) char smem[GEMM_LDS];
+    const int npairs = (nt + 2 * s - 1) / (2 * s);      // last one may have a short (or empty) B
+    int p = blockIdx.x / (s * s);
+    if (p > npairs - 1) p = npairs - 1;
+    int rem = blockIdx.x - p * s * s;
+    const int a0 = 2 * p * s;                            // A = [a0, a0+s), B = [a0+s, min(a0+2s, nt))
+    const int b0 = a0 + s;
+    int sb = nt - b0;
+    if (sb > s) sb = s;
+    const int ja = rem / sb, ib = rem % sb;              // tile in A (column block), tile in B (row block)
+    const int tj = a0 + ja, ti = b0 + ib;
+    d4 acc[4][4];
+    acc_zero(acc);
+    if (step == 1) {
+        tile_nt(U + (size_t)tj * TILE * ld, ld, L + (size_t)ti * TILE * ld, ld, tj * TILE, b0 * TILE, acc, smem);
+        tile_store(T + (size_t)tj * TILE * ld + ti * TILE, ld, acc, 1.0, 0.0);
+    } else {
+        tile_nt(T + (size_t)ti * TILE * ld, ld, T + (size_t)tj * TILE * ld, ld, b0 * TILE, (ti + 1) * TILE, acc,
+                smem);
+        tile_store(T + (size_t)ti * TILE * ld + tj * TILE, ld, acc, -1.0, 0.0);
+        tile_store_t(U + (size_t)tj * TILE * ld + ti * TILE, ld, acc, -1.0);
+    }
+}
+
+// ---- prediction: W[t][i] = sum_{k <= i} Ks[t][k] * T[i][k] ----
+__global__ __launch_bounds__(256, 2) void k_predict_gemm(const double* __restrict__ Ks, const double* __restrict__ T,
+                                                         double* __restrict__ W, int ld, int ntt, int nt)
+{
+    __shared__ __attribute__((aligned(16))) char smem[GEMM_LDS];
+    const int tt = blockIdx.x % ntt, ti = blockIdx.x / ntt;
+    d4 acc[4][4];
+    acc_zero(acc);
+    tile_nt(Ks + (size_t)tt * TILE * ld, ld, T + (size_t)ti * TILE * ld, ld, 0, (ti + 1) * TILE, acc, smem);
+    tile_store(W + (size_t)tt * TILE * ld + ti * TILE, ld, acc, 1.0, 0.0);
+}
+
+// ---- plain NT product for tests ----
+__global__ __launch_bounds__(256, 2) void k_test_gemm(const double* __restrict__ A, const double* __restrict__ B,
+                                                      double* __restrict__ C, int n, int k, int mt)
+{
+    __shared__ __attribute__((aligned(16))) char smem[GEMM_LDS];
+    const int ti = blockIdx.x % mt, tj = blockIdx.x / mt;
+    d4 acc[4][4];
+    acc_zero(acc);
+    tile_nt(A + (size_t)ti * TILE * k, k, B + (size_t)tj * TILE * k, k, 0, k, acc, smem);
+    tile_store(C + (size_t)ti * TILE * n + tj * TILE, n, acc, 1.0, 0.0);
+}
+
+__global__ __launch_bounds__(256) void k_mfma_peak(double* sink, int iters)
+{
+    d4 acc[8];
+    const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+#pragma unroll
+    for (int i = 0; i < 8; i++) acc[i] = (d4){0.0, 0.0, 0.0, 0.0};
+    for (int it = 0; it < iters; it++) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[i], 0, 0, 0);
+    }
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+    if (s == 12345.678) sink[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+// ------------------------------------------------------------------------------------------
+// SE covariance build: 64x64 tile per 256-thread workgroup, 4x4 outputs per thread, X tiles in LDS
+// ------------------------------------------------------------------------------------------
+constexpr int KT = 64;      // kernel-build tile
+constexpr int DC = 16;      // feature chunk staged per pass
+
+// squared distances of a 4x4 micro-tile, accumulated over d in index order without FMA
+// contraction so that the value matches the reference's sub / mul / add sequence bit for bit
+__device__ __forceinline__ void sqdist_4x4(const double* __restrict__ X, const double* __restrict__ Y, int nx,
+                                           int ny, int d, int i0, int j0, double (&xs)[KT][DC + 1],
+                                           double (&ys)[KT][DC + 1], double (&acc)[4][4])
+{
+#pragma clang fp contract(off)
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = 0.0;
+    for (int c0 = 0; c0 < d; c0 += DC) {
+        const int dc = (d - c0 < DC) ? (d - c0) : DC;
+        __syncthreads();
+        for (int e = t; e < KT * dc; e += 256) {
+            int r = e / dc, c = e - r * dc;
+            xs[r][c] = (i0 + r < nx) ? X[(size_t)(i0 + r) * d + c0 + c] : 0.0;
+            ys[r][c] = (j0 + r < ny) ? Y[(size_t)(j0 + r) * d + c0 + c] : 0.0;
+        }
+        __syncthreads();
+        for (int c = 0; c < dc; c++) {
+            double xv[4], yv[4];
+#pragma unroll
+            for (int a = 0; a < 4; a++) { xv[a] = xs[ty * 4 + a][c]; yv[a] = ys[tx * 4 + a][c]; }
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    double df = xv[a] - yv[b];
+                    acc[a][b] = acc[a][b] + df * df;
+                }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_build(const double* __restrict__ X, int n, int d, int npad,
+                                               HyperScalars h, double* __restrict__ K, int full)
+{
+    __shared__ double xs[KT][DC + 1], ys[KT][DC + 1];
+    int ti, tj;
+    tri_index(blockIdx.x, ti, tj);
+    const int i0 = ti * KT, j0 = tj * KT;
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    double d2v[4][4];
+    sqdist_4x4(X, X, n, n, d, i0, j0, xs, ys, d2v);
+    double out[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int i = i0 + ty * 4 + a, j = j0 + tx * 4 + b;
+            double v;
+            if (i < n && j < n) {
+                v = h.signal_var * exp(-d2v[a][b] * 0.5 / h.ell_sq);     // covkernel.cpp:89
+                if (i == j) v += h.noise_var;                            // covkernel.cpp:93-94
+            } else {
+                v = (i == j) ? 1.0 : 0.0;                                // identity padding
+            }
+            out[a][b] = v;
+        }
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        double* p = K + (size_t)(i0 + ty * 4 + a) * npad + j0 + tx * 4;
+        *(d2*)p = (d2){out[a][0], out[a][1]};
+        *(d2*)(p + 2) = (d2){out[a][2], out[a][3]};
+    }
+    if (full && ti != tj) {
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            double* p = K + (size_t)(j0 + tx * 4 + b) * npad + i0 + ty * 4;
+            *(d2*)p = (d2){out[0][b], out[1][b]};
+            *(d2*)(p + 2) = (d2){out[2][b], out[3][b]};
+        }
+    }
+}
+
+// Ks[t][i] = sf2 * exp(-0.5 |xt_t - x_i|^2 / l^2) (no noise, covkernel.cpp:105-116); zero padding
+__global__ __launch_bounds__(256) void k_cross(const double* __restrict__ X, int n, int d, int npad,
+                                               const double* __restrict__ Xt, int nt, int ntpad, HyperScalars h,
+                                               double* __restrict__ Ks)
+{
+    __shared__ double xs[KT][DC + 1], ys[KT][DC + 1];
+    const int tiles_i = npad / KT;
+    const int tt = blockIdx.x / tiles_i, ti = blockIdx.x % tiles_i;
+    const int t0 = tt * KT, i0 = ti * KT;
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    double d2v[4][4];
+    // the reference subtracts X[i] - xtest (covkernel.cpp:112); squares are sign-independent but keep the order
+    sqdist_4x4(Xt, X, nt, n, d, t0, i0, xs, ys, d2v);
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        const int tr = t0 + ty * 4 + a;
+        double o[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int i = i0 + tx * 4 + b;
+            o[b] = (tr < nt && i < n) ? h.signal_var * exp(-d2v[a][b] * 0.5 / h.ell_sq) : 0.0;
+        }
+        double* p = Ks + (size_t)tr * npad + i0 + tx * 4;
+        *(d2*)p = (d2){o[0], o[1]};
+        *(d2*)(p + 2) = (d2){o[2], o[3]};
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// diagonal block: 128x128 Cholesky in LDS (one workgroup), 16-wide inner blocks
+// ------------------------------------------------------------------------------------------
+constexpr int PLD = TILE + 1;                      // padded LDS row stride (doubles)
+constexpr int POTF2_LDS = TILE * PLD * 8;          // 132096 B
+constexpr int TRTRI_LDS = TILE * PLD * 8 + (TILE - 16) * 17 * 8;
+
+__global__ __launch_bounds__(256) void k_potf2(double* __restrict__ A, int ld, int kb, double* __restrict__ d16,
+                                               double* __restrict__ logdet_part)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ double dinv[16][17];
+    __shared__ double red[TILE];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    double* Ab = A + (size_t)kb * TILE * ld + kb * TILE;
+
+    for (int e = t; e < TILE * TILE; e += 256) {
+        int r = e >> 7, c = e & 127;
+        sm[r * PLD + c] = (c <= r) ? Ab[(size_t)r * ld + c] : 0.0;
+    }
+    __syncthreads();
+
+    for (int jb = 0; jb < TILE / 16; jb++) {
+        const int j0 = jb * 16;
+        if (wave == 0) {
+            // lane l (< 16) owns row l of the 16x16 diagonal block; lanes >= 16 mirror lane l & 15
+            const int l = lane & 15;
+            double r[16];
+#pragma unroll
+            for (int c = 0; c < 16; c++) r[c] = sm[(j0 + l) * PLD + j0 + c];
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+                const double piv = __shfl(r[c], c, 64);
+                const double dg = sqrt(piv);                 // non-PD => NaN, flows on (never traps)
+                const double lc = (l == c) ? dg : r[c] / dg;
+                r[c] = lc;
+#pragma unroll
+                for (int c2 = c + 1; c2 < 16; c2++) {
+                    const double o = __shfl(lc, c2, 64);
+                    r[c2] -= lc * o;
+                }
+            }
+            // inverse of the 16x16 factor: lane j builds column j of Tinv by forward substitution
+            double tc[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                double s = (i == l) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < i; k++) {
+                    const double lik = __shfl(r[k], i, 64);
+                    s -= lik * tc[k];
+                }
+                const double lii = __shfl(r[i], i, 64);
+                tc[i] = s / lii;
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int c = 0; c < 16; c++) sm[(j0 + l) * PLD + j0 + c] = (c <= l) ? r[c] : 0.0;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    dinv[i][l] = tc[i];
+                    d16[((size_t)kb * 8 + jb) * 256 + i * 16 + l] = tc[i];
+                }
+            }
+        }
+        __syncthreads();
+        const int m = TILE - j0 - 16;                         // rows below the diagonal block
+        if (m > 0) {
+            // panel: X[i][c] = sum_{k<=c} A[i][j0+k] * Dinv[c][k]
+            double xs[7];
+#pragma unroll
+            for (int q = 0; q < 7; q++) {
+                const int e = t + 256 * q;
+                double sacc = 0.0;
+                if (e < m * 16) {
+                    const int i = j0 + 16 + (e >> 4), c = e & 15;
+                    for (int k = 0; k <= c; k++) sacc += sm[i * PLD + j0 + k] * dinv[c][k];
+                }
+                xs[q] = sacc;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 7; q++) {
+                const int e = t + 256 * q;
+                if (e < m * 16) {
+                    const int i = j0 + 16 + (e >> 4), c = e & 15;
+                    sm[i * PLD + j0 + c] = xs[q];
+                }
+            }
+            __syncthreads();
+            // trailing update of the lower triangle: A[i][c] -= sum_k X[i][k] X[c][k]
+            for (int e = t; e < m * m; e += 256) {
+                const int i = j0 + 16 + e / m, c = j0 + 16 + e % m;
+                if (c <= i) {
+                    double s = 0.0;
+#pragma unroll
+                    for (int k = 0; k < 16; k++) s += sm[i * PLD + j0 + k] * sm[c * PLD + j0 + k];
+                    sm[i * PLD + c] -= s;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int e = t; e < TILE * TILE; e += 256) {
+        int r = e >> 7, c = e & 127;
+        if (c <= r) Ab[(size_t)r * ld + c] = sm[r * PLD + c];
+    }
+    // log-determinant share of this block, summed in a fixed order
+    if (t < TILE) red[t] = log(sm[t * PLD + t]);
+    __syncthreads();
+    for (int w = TILE / 2; w > 0; w >>= 1) {
+        if (t < w) red[t] += red[t + w];
+        __syncthreads();
+    }
+    if (t == 0) logdet_part[kb] = red[0];
+}
+
+// inverse of a 128x128 diagonal factor block from its 16x16 diagonal inverses (blocked, right to left);
+// writes T (lower, zeros above) and U = T^T (upper, zeros below).  blockIdx.x = block offset from kb.
+__global__ __launch_bounds__(256) void k_trtri_diag(const double* __restrict__ A, int ld, int kb,
+                                                    const double* __restrict__ d16, double* __restrict__ T,
+                                                    double* __restrict__ U)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* ytmp = sm + TILE * PLD;                             // [(TILE-16)][17]
+    const int t = threadIdx.x;
+    const int b = kb + blockIdx.x;
+    const double* Ab = A + (size_t)b * TILE * ld + b * TILE;
+    const double* db = d16 + (size_t)b * 8 * 256;
+
+    for (int e = t; e < TILE * TILE; e += 256) {
+        int r = e >> 7, c = e & 127;
+        sm[r * PLD + c] = (c <= r) ? Ab[(size_t)r * ld + c] : 0.0;
+    }
+    __syncthreads();
+    for (int jb = TILE / 16 - 1; jb >= 0; jb--) {
+        const int j0 = jb * 16;
+        const int m = TILE - j0 - 16;
+        const double* dj = db + jb * 256;
+        if (m > 0) {
+            // Y[i][c] = sum_{k=j0+16..i} T[i][k] * L[k][j0+c]
+            for (int e = t; e < m * 16; e += 256) {
+                const int ii = e >> 4, c = e & 15;
+                const int i = j0 + 16 + ii;
+                double s = 0.0;
+                for (int k = j0 + 16; k <= i; k++) s += sm[i * PLD + k] * sm[k * PLD + j0 + c];
+                ytmp[ii * 17 + c] = s;
+            }
+            __syncthreads();
+            // T21[i][c] = -sum_{k>=c} Y[i][k] * D[k][c]
+            for (int e = t; e < m * 16; e += 256) {
+                const int ii = e >> 4, c = e & 15;
+                double s = 0.0;
+                for (int k = c; k < 16; k++) s += ytmp[ii * 17 + k] * dj[k * 16 + c];
+                sm[(j0 + 16 + ii) * PLD + j0 + c] = -s;
+            }
+        }
+        __syncthreads();
+        if (t < 256) {
+            const int i = t >> 4, c = t & 15;
+            sm[(j0 + i) * PLD + j0 + c] = (c <= i) ? dj[i * 16 + c] : 0.0;
+        }
+        __syncthreads();
+    }
+    double* Tb = T + (size_t)b * TILE * ld + b * TILE;
+    double* Ub = U + (size_t)b * TILE * ld + b * TILE;
+    for (int e = t; e < TILE * TILE; e += 256) {
+        int r = e >> 7, c = e & 127;
+        Tb[(size_t)r * ld + c] = sm[r * PLD + c];          // upper part already zero
+        Ub[(size_t)r * ld + c] = sm[c * PLD + r];          // transpose
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// vector kernels
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// z[i] = sum_{k < (ti+1)*128} T[i][k] x[k]  (one wave per row; the diagonal tile is zero above the diagonal)
+__global__ __launch_bounds__(256) void k_trmv_lower(const double* __restrict__ T, int ld, int npad,
+                                                    const double* __restrict__ x, double* __restrict__ z)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= npad) return;
+    const int kend = (row / TILE + 1) * TILE;
+    const double* tr = T + (size_t)row * ld;
+    double s = 0.0;
+    for (int k = lane * 2; k < kend; k += 128) {
+        d2 v = *(const d2*)(tr + k), xv = *(const d2*)(x + k);
+        s += v[0] * xv[0] + v[1] * xv[1];
+    }
+    s = wave_sum(s);
+    if (lane == 0) z[row] = s;
+}
+
+// a[i] = sum_{k >= ti*128} U[i][k] x[k]
+__global__ __launch_bounds__(256) void k_trmv_upper(const double* __restrict__ U, int ld, int npad,
+                                                    const double* __restrict__ x, double* __restrict__ a)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= npad) return;
+    const int kbeg = (row / TILE) * TILE;
+    const double* ur = U + (size_t)row * ld;
+    double s = 0.0;
+    for (int k = kbeg + lane * 2; k < npad; k += 128) {
+        d2 v = *(const d2*)(ur + k), xv = *(const d2*)(x + k);
+        s += v[0] * xv[0] + v[1] * xv[1];
+    }
+    s = wave_sum(s);
+    if (lane == 0) a[row] = s;
+}
+
+// blocked forward substitution L z = y (LL-only path): step kb = (1) z_kb = T_kk w_kb, (2) w[rows below] -= L21 z_kb
+__global__ __launch_bounds__(256) void k_trsv_diag(const double* __restrict__ T, int ld, int kb,
+                                                   const double* __restrict__ w, double* __restrict__ z)
+{
+    const int k0 = kb * TILE;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int r = wave; r < TILE; r += 4) {
+        const double* tr = T + (size_t)(k0 + r) * ld + k0;
+        d2 v = *(const d2*)(tr + lane * 2), xv = *(const d2*)(w + k0 + lane * 2);
+        double s = wave_sum(v[0] * xv[0] + v[1] * xv[1]);
+        if (lane == 0) z[k0 + r] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_trsv_update(const double* __restrict__ A, int ld, int kb, int npad,
+                                                     const double* __restrict__ z, double* __restrict__ w)
+{
+    const int k0 = kb * TILE;
+    const int row = k0 + TILE + blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= npad) return;
+    const double* ar = A + (size_t)row * ld + k0;
+    d2 v = *(const d2*)(ar + lane * 2), xv = *(const d2*)(z + k0 + lane * 2);
+    double s = wave_sum(v[0] * xv[0] + v[1] * xv[1]);
+    if (lane == 0) w[row] -= s;
+}
+
+// gradient traces, fused: for every lower 64x64 tile recompute k(xi,xj) and |xi-xj|^2/l^2, read K^-1 once,
+// W = K^-1 - alpha alpha^T, accumulate  s1 = sum W*K*S, s2 = sum W*K, s3 = sum_i W_ii  (off-diagonal tiles x2)
+__global__ __launch_bounds__(256) void k_trace(const double* __restrict__ X, int n, int d, int npad, HyperScalars h,
+                                               const double* __restrict__ Kinv, const double* __restrict__ alpha,
+                                               double* __restrict__ part)
+{
+    __shared__ double xs[KT][DC + 1], ys[KT][DC + 1];
+    __shared__ double red[3][4];
+    int ti, tj;
+    tri_index(blockIdx.x, ti, tj);
+    const int i0 = ti * KT, j0 = tj * KT;
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    double d2v[4][4];
+    sqdist_4x4(X, X, n, n, d, i0, j0, xs, ys, d2v);
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    double aj[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) aj[b] = alpha[j0 + tx * 4 + b];
+#pragma unroll
+    for (int a = 0; a < 4; a++) {
+        const int i = i0 + ty * 4 + a;
+        const double ai = alpha[i];
+        const double* kr = Kinv + (size_t)i * npad + j0 + tx * 4;
+        d2 k01 = *(const d2*)kr, k23 = *(const d2*)(kr + 2);
+        const double kv[4] = {k01[0], k01[1], k23[0], k23[1]};
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const int j = j0 + tx * 4 + b;
+            if (i < n && j < n && (ti != tj || j <= i)) {
+                const double w = kv[b] - ai * aj[b];
+                double kse = h.signal_var * exp(-d2v[a][b] * 0.5 / h.ell_sq);
+                const double sd = d2v[a][b] / h.ell_sq;
+                if (i == j) {
+                    kse += h.noise_var;
+                    s1 += w * (kse * sd);
+                    s2 += w * kse;
+                    s3 += w;
+                } else {
+                    s1 += 2.0 * (w * (kse * sd));
+                    s2 += 2.0 * (w * kse);
+                }
+            }
+        }
+    }
+    s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
+    if ((t & 63) == 0) { red[0][t >> 6] = s1; red[1][t >> 6] = s2; red[2][t >> 6] = s3; }
+    __syncthreads();
+    if (t < 3) part[(size_t)blockIdx.x * 3 + t] = (red[t][0] + red[t][1]) + (red[t][2] + red[t][3]);
+}
+
+// single workgroup: deterministic final sums and the scalar formulas
+//   LL = -0.5 (z'z + 2 sum log L_ii + n * 1.83787)                     covkernel.cpp:127
+//   g0 = s1/2, g1 = (2 s2 - 2 sn2 s3)/2, g2 = (2 sn2 s3)/2              covkernel.cpp:244-261
+__global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ z, int npad, int n,
+                                                  const double* __restrict__ logdet_part, int nt,
+                                                  const double* __restrict__ part, int nblocks, HyperScalars h,
+                                                  double* __restrict__ out)
+{
+    __shared__ double red[5][256];
+    const int t = threadIdx.x;
+    double q = 0.0, ld = 0.0, s[3] = {0.0, 0.0, 0.0};
+    for (int i = t; i < npad; i += 256) q += z[i] * z[i];
+    for (int i = t; i < nt; i += 256) ld += logdet_part[i];
+    if (part)
+        for (int i = t; i < nblocks; i += 256) {
+            s[0] += part[(size_t)i * 3]; s[1] += part[(size_t)i * 3 + 1]; s[2] += part[(size_t)i * 3 + 2];
+        }
+    red[0][t] = q; red[1][t] = ld; red[2][t] = s[0]; red[3][t] = s[1]; red[4][t] = s[2];
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w)
+            for (int c = 0; c < 5; c++) red[c][t] += red[c][t + w];
+        __syncthreads();
+    }
+    if (t == 0) {
+        const double quad = red[0][0], logdet = 2 * red[1][0];
+        out[0] = -0.5 * (quad + logdet + n * 1.83787);
+        if (part) {
+            const double s1 = red[2][0], s2 = red[3][0], s3 = red[4][0];
+            out[1] = s1 / 2.0;
+            out[2] = (2.0 * s2 - 2.0 * h.noise_var * s3) / 2.0;
+            out[3] = (2.0 * h.noise_var * s3) / 2.0;
+        }
+        out[4] = quad;
+        out[5] = logdet;
+    }
+}
+
+// mean[t] = Ks[t] . alpha ; var[t] = sf2 + sn2 - |W[t]|^2        covkernel.cpp:314-319
+__global__ __launch_bounds__(256) void k_predict_finish(const double* __restrict__ Ks, const double* __restrict__ W,
+                                                        const double* __restrict__ alpha, int n, int npad,
+                                                        int ntest, HyperScalars h, double* __restrict__ mean,
+                                                        double* __restrict__ var)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= ntest) return;
+    const double* kr = Ks + (size_t)row * npad;
+    const double* wr = W + (size_t)row * npad;
+    double m = 0.0, q = 0.0;
+    for (int k = lane * 2; k < npad; k += 128) {
+        d2 kv = *(const d2*)(kr + k), av = *(const d2*)(alpha + k), wv = *(const d2*)(wr + k);
+        m += kv[0] * av[0] + kv[1] * av[1];
+        q += wv[0] * wv[0] + wv[1] * wv[1];
+    }
+    m = wave_sum(m); q = wave_sum(q);
+    if (lane == 0) { mean[row] = m; var[row] = h.signal_var + h.noise_var - q; }
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+static inline int tri_count(int n) { return n * (n + 1) / 2; }
+
+void launch_kbuild(const double* X, int n, int d, int npad, HyperScalars h, double* K, bool full, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_build, dim3(tri_count(npad / KT)), dim3(256), 0, s, X, n, d, npad, h, K, full ? 1 : 0);
+}
+
+void launch_kcross(const double* X, int n, int d, int npad, const double* Xt, int nt, int ntpad, HyperScalars h,
+                   double* Ks, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_cross, dim3((ntpad / KT) * (npad / KT)), dim3(256), 0, s, X, n, d, npad, Xt, nt, ntpad, h,
+                       Ks);
+}
+
+static bool g_attr_done = false;
+static void set_big_lds()
+{
+    if (g_attr_done) return;
+    (void)hipFuncSetAttribute((const void*)k_potf2, hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_LDS);
+    (void)hipFuncSetAttribute((const void*)k_trtri_diag, hipFuncAttributeMaxDynamicSharedMemorySize, TRTRI_LDS);
+    g_attr_done = true;
+}
+
+void launch_potf2(double* A, int ld, int kb, double* d16, double* logdet_part, hipStream_t s)
+{
+    set_big_lds();
+    hipLaunchKernelGGL(k_potf2, dim3(1), dim3(256), POTF2_LDS, s, A, ld, kb, d16, logdet_part);
+}
+
+void launch_trtri_diag(const double* A, int ld, int kb, int nblocks, const double* d16, double* T, double* U,
+                       hipStream_t s)
+{
+    set_big_lds();
+    hipLaunchKernelGGL(k_trtri_diag, dim3(nblocks), dim3(256), TRTRI_LDS, s, A, ld, kb, d16, T, U);
+}
+
+void launch_trsm_panel(double* A, const double* T, int ld, int kb, int nt, hipStream_t s)
+{
+    const int m = nt - kb - 1;
+    if (m <= 0) return;
+    hipLaunchKernelGGL(k_trsm_panel, dim3(m), dim3(256), 0, s, A, T, ld, kb);
+}
+
+void launch_syrk_trail(double* A, int ld, int kb, int nt, hipStream_t s)
+{
+    const int m = nt - kb - 1;
+    if (m <= 0) return;
+    hipLaunchKernelGGL(k_syrk_trail, dim3(tri_count(m)), dim3(256), 0, s, A, ld, kb);
+}
+
+void launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, int s, int step, hipStream_t st)
+{
+    // pairs p = 0.. : A = [2ps, 2ps+s), B = [2ps+s, min(2ps+2s, nt)); count tiles |A| x |B|
+    int tiles = 0;
+    for (int a0 = 0; a0 + s < nt; a0 += 2 * s) {
+        int sb = nt - (a0 + s);
+        if (sb > s) sb = s;
+        tiles += s * sb;
+    }
+    if (tiles <= 0) return;
+    hipLaunchKernelGGL(k_trtri_level, dim3(tiles), dim3(256), 0, st, L, T, U, ld, nt, s, step);
+}
+
+void launch_lauum(const double* U, double* Kinv, int ld, int nt, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_lauum, dim3(tri_count(nt)), dim3(256), 0, s, U, Kinv, ld, nt);
+}
+
+void launch_predict_gemm(const double* Ks, const double* T, double* W, int ld, int ntt, int nt, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_predict_gemm, dim3(ntt * nt), dim3(256), 0, s, Ks, T, W, ld, ntt, nt);
+}
+
+void launch_predict_finish(const double* Ks, const double* W, const double* alpha, int n, int npad, int ntest,
+                           HyperScalars h, double* mean, double* var, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_predict_finish, dim3((ntest + 3) / 4), dim3(256), 0, s, Ks, W, alpha, n, npad, ntest, h,
+                       mean, var);
+}
+
+void launch_trmv_lower(const double* T, int ld, int npad, const double* x, double* z, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_trmv_lower, dim3(npad / 4), dim3(256), 0, s, T, ld, npad, x, z);
+}
+
+void launch_trmv_upper(const double* U, int ld, int npad, const double* x, double* a, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_trmv_upper, dim3(npad / 4), dim3(256), 0, s, U, ld, npad, x, a);
+}
+
+void launch_trsv_lower(const double* A, const double* T, int ld, int nt, const double* y, double* z, hipStream_t s)
+{
+    // y is consumed as the running right-hand side w (caller passes a scratch copy)
+    double* w = const_cast<double*>(y);
+    const int npad = nt * TILE;
+    for (int kb = 0; kb < nt; kb++) {
+        hipLaunchKernelGGL(k_trsv_diag, dim3(1), dim3(256), 0, s, T, ld, kb, w, z);
+        const int rows = npad - (kb + 1) * TILE;
+        if (rows > 0)
+            hipLaunchKernelGGL(k_trsv_update, dim3(rows / 4), dim3(256), 0, s, A, ld, kb, npad, z, w);
+    }
+}
+
+int trace_num_blocks(int npad) { return tri_count(npad / KT); }
+
+void launch_trace(const double* X, int n, int d, int npad, HyperScalars h, const double* Kinv, const double* alpha,
+                  double* part, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_trace, dim3(tri_count(npad / KT)), dim3(256), 0, s, X, n, d, npad, h, Kinv, alpha, part);
+}
+
+void launch_finalize(const double* z, int npad, int n, const double* logdet_part, int nt, const double* part,
+                     int nblocks, HyperScalars h, double* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, z, npad, n, logdet_part, nt, part, nblocks, h, out);
+}
+
+void launch_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, int k, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_test_gemm, dim3((m / TILE) * (n / TILE)), dim3(256), 0, s, A, B, C, n, k, m / TILE);
+}
+
+void launch_mfma_peak(double* sink, int blocks, int iters, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_mfma_peak, dim3(blocks), dim3(256), 0, s, sink, iters);
+}
+
+}  // namespace cugp

@@ -1,0 +1,346 @@
+"""Python mirror of the reference's host interface over the C-ABI.
+
+`Covsum` keeps the method names and argument meaning of the reference class
+(cpp_serial_gp/covkernel.h:20-37); `BCM` those of distributed_gp/BCM.h:15-26.  Every method is a
+thin call into libcugp.so -- no arithmetic happens in Python.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import check, f64, ptr
+
+
+class Covsum:
+    """One GP expert on one GPU.  Covsum(n, d) as covkernel.cpp:14-37; X, y are given per call as in
+    the reference and uploaded when they change (identity of the arrays is the cache key)."""
+
+    def __init__(self, n, d, device=0):
+        self.n, self.d, self.device = int(n), int(d), int(device)
+        self._h = C.c_void_p()
+        check(capi.lib().cugp_create(self.n, self.d, self.device, C.byref(self._h)))
+        self._data_key = None
+
+    # -- lifetime --
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            capi.lib().cugp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    # -- data --
+    def set_data(self, X, y):
+        X, y = f64(X), f64(y)
+        if X.shape != (self.n, self.d) or y.shape != (self.n,):
+            raise ValueError("expected X %s and y %s" % ((self.n, self.d), (self.n,)))
+        check(capi.lib().cugp_set_data(self._h, ptr(X), ptr(y)))
+        self._data_key = None
+
+    def set_data_device(self, dX_ptr, dy_ptr):
+        check(capi.lib().cugp_set_data_device(self._h, C.c_void_p(dX_ptr), C.c_void_p(dy_ptr)))
+        self._data_key = None
+
+    def _bind(self, X, y):
+        if X is None:
+            return
+        key = (id(X), id(y))
+        if key != self._data_key:
+            self.set_data(X, y)
+            self._data_key = key
+
+    # -- hyper-parameters --
+    def set_loghyperparam(self, hp):
+        check(capi.lib().cugp_set_loghyper(self._h, ptr(f64(hp))))
+
+    set_loghyper_eigen = set_loghyperparam
+
+    def get_loghyperparam(self):
+        out = np.empty(3)
+        check(capi.lib().cugp_get_loghyper(self._h, ptr(out)))
+        return out
+
+    def get_param_dim(self):
+        return self.d            # covkernel.cpp:661-663 returns numdim
+
+    # -- objective --
+    def compute_loglikelihood(self, X=None, y=None):
+        self._bind(X, y)
+        ll = C.c_double()
+        check(capi.lib().cugp_loglik(self._h, C.byref(ll)))
+        return ll.value
+
+    def compute_gradient_loghyperparam(self, X=None, y=None):
+        self._bind(X, y)
+        g = np.empty(3)
+        check(capi.lib().cugp_grad(self._h, ptr(g)))
+        return g
+
+    def loglik_grad(self, X=None, y=None):
+        self._bind(X, y)
+        ll = C.c_double()
+        g = np.empty(3)
+        check(capi.lib().cugp_loglik_grad(self._h, C.byref(ll), ptr(g)))
+        return ll.value, g
+
+    def enqueue(self, want_grad=True):
+        check(capi.lib().cugp_loglik_grad_enqueue(self._h, 1 if want_grad else 0))
+
+    def fetch(self):
+        ll = C.c_double()
+        g = np.empty(3)
+        check(capi.lib().cugp_loglik_grad_fetch(self._h, C.byref(ll), ptr(g)))
+        return ll.value, g
+
+    def last_quad_logdet(self):
+        q, d = C.c_double(), C.c_double()
+        check(capi.lib().cugp_last_quad_logdet(self._h, C.byref(q), C.byref(d)))
+        return q.value, d.value
+
+    # -- intermediates --
+    def compute_K_train(self, X=None):
+        """Covsum::compute_K_train(X, out): the full symmetric n x n covariance (labels are not used)."""
+        if X is not None and (self._data_key is None or self._data_key[0] != id(X)):
+            self.set_data(X, np.zeros(self.n))
+            self._data_key = (id(X), None)
+        K = np.empty((self.n, self.n))
+        check(capi.lib().cugp_compute_K_train(self._h, ptr(K)))
+        return K
+
+    def compute_k_test(self, Xt):
+        Xt = f64(Xt).reshape(-1, self.d)
+        Ks = np.empty((Xt.shape[0], self.n))
+        check(capi.lib().cugp_compute_k_test(self._h, ptr(Xt), Xt.shape[0], ptr(Ks)))
+        return Ks
+
+    def get_cholesky(self):
+        L = np.empty((self.n, self.n))
+        check(capi.lib().cugp_get_cholesky(self._h, ptr(L)))
+        return L
+
+    def get_K_inverse(self):
+        Ki = np.empty((self.n, self.n))
+        check(capi.lib().cugp_get_K_inverse(self._h, ptr(Ki)))
+        return Ki
+
+    def get_alpha(self):
+        a = np.empty(self.n)
+        check(capi.lib().cugp_get_alpha(self._h, ptr(a)))
+        return a
+
+    # -- prediction --
+    def compute_test_means_and_variances(self, X, y, Xtest):
+        self._bind(X, y)
+        Xt = f64(Xtest).reshape(-1, self.d)
+        m, v = np.empty(Xt.shape[0]), np.empty(Xt.shape[0])
+        check(capi.lib().cugp_predict(self._h, ptr(Xt), Xt.shape[0], ptr(m), ptr(v)))
+        return m, v
+
+    @staticmethod
+    def get_negative_log_predprob(actual, predmean, predvar):
+        a, m, v = f64(actual), f64(predmean), f64(predvar)
+        out = C.c_double()
+        check(capi.lib().cugp_nlpp(ptr(a), ptr(m), ptr(v), a.shape[0], C.byref(out)))
+        return out.value
+
+    # -- optimisers --
+    def cg_solve(self, X=None, y=None, budget=100):
+        """Covsum::cg_solve; returns the evaluation trace [n_evals, 4] = (hp0, hp1, hp2, -LL)."""
+        self._bind(X, y)
+        tr = np.zeros((4 * budget + 8, 4))
+        ne = C.c_int()
+        check(capi.lib().cugp_cg_solve(self._h, budget, ptr(tr), tr.shape[0], C.byref(ne)))
+        return tr[: ne.value]
+
+    def rprop_solve(self, X=None, y=None, iters=100):
+        self._bind(X, y)
+        tr = np.zeros((2 * iters + 8, 4))
+        ne = C.c_int()
+        check(capi.lib().cugp_rprop_solve(self._h, iters, ptr(tr), tr.shape[0], C.byref(ne)))
+        return tr[: ne.value]
+
+    # -- timing --
+    def set_profiling(self, level):
+        check(capi.lib().cugp_set_profiling(self._h, int(level)))
+
+    def phase_ms(self):
+        ms = np.empty(6)
+        check(capi.lib().cugp_get_phase_ms(self._h, ptr(ms)))
+        return dict(zip(("kbuild", "potrf", "trtri", "lauum", "tail", "total"), ms.tolist()))
+
+    def kernel_stats(self, reset=False):
+        s, n, f = C.c_double(), C.c_longlong(), C.c_double()
+        check(capi.lib().cugp_get_kernel_stats(self._h, C.byref(s), C.byref(n), C.byref(f), 1 if reset else 0))
+        return {"sum_ms": s.value, "launches": n.value, "flop": f.value}
+
+
+class BCM:
+    """Experts resident on ONE GPU (class BCM, distributed_gp/BCM.h).  `BCM.split` reproduces the
+    reference constructor's row partition (BCM.cpp:85-110)."""
+
+    def __init__(self, rows, d, device=0):
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        self.rows, self.d, self.device = rows.tolist(), int(d), int(device)
+        self._h = C.c_void_p()
+        check(capi.lib().cugp_bcm_create(len(self.rows), rows.ctypes.data_as(capi._ip), self.d, self.device,
+                                         C.byref(self._h)))
+
+    @classmethod
+    def split(cls, X, y, K, device=0):
+        X, y = f64(X), f64(y)
+        N, D = X.shape
+        part = N // K
+        rows = [part] * (K - 1) + [N - part * (K - 1)]
+        b = cls(rows, D, device)
+        off = 0
+        for k in range(K):
+            b.set_expert_data(k, X[off: off + rows[k]], y[off: off + rows[k]])
+            off += part
+        return b
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            capi.lib().cugp_bcm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_expert_data(self, k, X, y):
+        X, y = f64(X), f64(y)
+        check(capi.lib().cugp_bcm_set_expert_data(self._h, k, ptr(X), ptr(y)))
+
+    def set_BCM_log_hyperparam(self, hp):
+        check(capi.lib().cugp_bcm_set_loghyper(self._h, ptr(f64(hp))))
+
+    set_BCM_loghyper_eigen = set_BCM_log_hyperparam
+
+    def get_loghyperparam(self):
+        out = np.empty(3)
+        check(capi.lib().cugp_bcm_get_loghyper(self._h, ptr(out)))
+        return out
+
+    def loglik_grad(self):
+        """-> (sum LL, sum grad[3], per-expert LL) over the experts of this GPU."""
+        ll = C.c_double()
+        g = np.empty(3)
+        per = np.empty(len(self.rows))
+        check(capi.lib().cugp_bcm_loglik_grad(self._h, C.byref(ll), ptr(g), ptr(per)))
+        return ll.value, g, per
+
+    def get_BCM_loglikelihood(self):
+        return self.loglik_grad()[0]
+
+    def get_BCM_gradient_hyper(self):
+        return self.loglik_grad()[1]
+
+    def predict_partial(self, Xt):
+        Xt = f64(Xt).reshape(-1, self.d)
+        sp, spm = np.empty(Xt.shape[0]), np.empty(Xt.shape[0])
+        check(capi.lib().cugp_bcm_predict_partial(self._h, ptr(Xt), Xt.shape[0], ptr(sp), ptr(spm)))
+        return sp, spm
+
+    def compute_BCM_test_means_and_var(self, Xt):
+        Xt = f64(Xt).reshape(-1, self.d)
+        m, v = np.empty(Xt.shape[0]), np.empty(Xt.shape[0])
+        check(capi.lib().cugp_bcm_predict(self._h, ptr(Xt), Xt.shape[0], ptr(m), ptr(v)))
+        return m, v
+
+    get_BCM_negative_log_predprob = staticmethod(Covsum.get_negative_log_predprob)
+
+    def cg_solve(self, budget=100):
+        tr = np.zeros((4 * budget + 8, 4))
+        ne = C.c_int()
+        check(capi.lib().cugp_bcm_cg_solve(self._h, budget, ptr(tr), tr.shape[0], C.byref(ne)))
+        return tr[: ne.value]
+
+
+def poe_finish(sum_prec, sum_prec_mean):
+    sp, spm = f64(sum_prec), f64(sum_prec_mean)
+    m, v = np.empty_like(sp), np.empty_like(sp)
+    check(capi.lib().cugp_poe_finish(ptr(sp), ptr(spm), sp.shape[0], ptr(m), ptr(v)))
+    return m, v
+
+
+def cg_minimize(fn, theta, budget=100):
+    """Host CG loop of the library on a Python objective fn(theta)->(f, g)."""
+    def cb(_ctx, th, f, g):
+        fv, gv = fn(np.array([th[0], th[1], th[2]]))
+        f[0] = fv
+        for i in range(3):
+            g[i] = gv[i]
+    th = f64(theta).copy()
+    tr = np.zeros((4 * budget + 8, 4))
+    ne = C.c_int()
+    check(capi.lib().cugp_cg_minimize(capi.OBJECTIVE(cb), None, ptr(th), budget, ptr(tr), tr.shape[0],
+                                      C.byref(ne)))
+    return th, tr[: ne.value]
+
+
+def rprop_minimize(fn, theta, iters=100):
+    def cb(_ctx, th, f, g):
+        fv, gv = fn(np.array([th[0], th[1], th[2]]))
+        f[0] = fv
+        for i in range(3):
+            g[i] = gv[i]
+    th = f64(theta).copy()
+    tr = np.zeros((2 * iters + 8, 4))
+    ne = C.c_int()
+    check(capi.lib().cugp_rprop_minimize(capi.OBJECTIVE(cb), None, ptr(th), iters, ptr(tr), tr.shape[0],
+                                         C.byref(ne)))
+    return th, tr[: ne.value]
+
+
+def test_gemm_nt(A, B, device=0):
+    A, B = f64(A), f64(B)
+    m, k = A.shape
+    n = B.shape[0]
+    Cm = np.empty((m, n))
+    check(capi.lib().cugp_test_gemm_nt(m, n, k, ptr(A), ptr(B), ptr(Cm), device))
+    return Cm
+
+
+def mfma_peak_tflops(device=0):
+    out = C.c_double()
+    check(capi.lib().cugp_mfma_peak_tflops(device, C.byref(out)))
+    return out.value
+
+
+def potrf(K, device=0):
+    K = f64(K)
+    L = np.empty_like(K)
+    check(capi.lib().cugp_potrf(K.shape[0], ptr(K), ptr(L), device))
+    return L
+
+
+def potri(K, device=0):
+    K = f64(K)
+    Ki = np.empty_like(K)
+    check(capi.lib().cugp_potri(K.shape[0], ptr(K), ptr(Ki), device))
+    return Ki
+
+
+def chol_and_det(K, y, device=0):
+    K, y = f64(K), f64(y)
+    q, d = C.c_double(), C.c_double()
+    check(capi.lib().cugp_chol_and_det(K.shape[0], ptr(K), ptr(y), C.byref(q), C.byref(d), device))
+    return q.value, d.value
+
+
+def potrs_vec(K, y, device=0):
+    K, y = f64(K), f64(y)
+    x = np.empty(K.shape[0])
+    check(capi.lib().cugp_potrs_vec(K.shape[0], ptr(K), ptr(y), ptr(x), device))
+    return x

@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/* from the reference itself.  Run HERE (the container
+with /root/reference); the GPU box only ever sees the committed outputs.
+
+    python tests/golden/make_golden.py            # small cases  (~2 min)
+    python tests/golden/make_golden.py --big 4096 # adds sine_4096 LL+grad (~15 min, 1 core)
+    python tests/golden/make_golden.py --big 8192 # adds siproper_8192 LL+grad (~2.5 h, 1 core)
+
+Inputs  : the reference's data files (chunked_dataset/*.txt) -> data_*.npz
+Outputs : expected values computed by the reference's own C++ compiled where it
+          lies (oracle/Makefile -> oracle/_ref/libref_*.so) -> golden_*.json
+Also    : the numeric trace of the reference's committed run log
+          cuda_bettersinglenode_ver2/REF -> ref_log_si128.json
+
+Only data (inputs, expected outputs) is written; no reference source text.
+"""
+import argparse
+import json
+import os
+import re
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = os.environ.get("CUGP_REFERENCE", "/root/reference")
+DS = os.path.join(REF, "chunked_dataset")
+
+HP_DEFAULT = [0.5, 0.5, 0.5]                      # cpp_serial_gp/serial_gp.cpp:49
+HP_BCM = [1.5, 1.5, 1.5]                          # distributed_gp/distributed_ver1.cpp:274
+HP_DENSE = [3.762111, -1.152105, -0.384461]       # cuda_src/main.cpp:190-193
+
+
+def load_txt(prefix, rows=None):
+    X = np.loadtxt(os.path.join(DS, prefix + "_chunk0.txt"), skiprows=1, max_rows=rows)
+    y = np.loadtxt(os.path.join(DS, prefix + "_label0.txt"), max_rows=rows)
+    return np.ascontiguousarray(X), np.ascontiguousarray(y)
+
+
+def parse_please_see(path):
+    """-> list of [kind, hp0, hp1, hp2] from a cg_solve stdout capture."""
+    out = []
+    pat = re.compile(r"PLEASE-SEE\s+(\d)\s*:\s*([-\d.eE+naninf]+),\s*([-\d.eE+naninf]+),\s*([-\d.eE+naninf]+)")
+    with open(path, errors="replace") as f:
+        for line in f:
+            m = pat.search(line)
+            if m:
+                out.append([int(m.group(1))] + [float(m.group(i)) for i in (2, 3, 4)])
+    return out
+
+
+def dump(name, obj):
+    with open(os.path.join(HERE, name), "w") as f:
+        json.dump(obj, f, indent=1)
+    print("wrote", name)
+
+
+def ll_grad(r, X, y, hp):
+    t0 = time.time()
+    ll = r.loglik(X, y, hp)
+    t1 = time.time()
+    g = r.grad(X, y, hp)
+    t2 = time.time()
+    return {"hp": list(hp), "n": int(X.shape[0]), "ll": ll, "grad": g.tolist(),
+            "t_ll_s": round(t1 - t0, 4), "t_grad_s": round(t2 - t1, 4)}
+
+
+def small(r):
+    tmp = tempfile.mkdtemp()
+    # ---- data fixtures -------------------------------------------------
+    Xs = np.vstack([np.loadtxt(os.path.join(DS, f"si32_chunk{i}.txt"), skiprows=1) for i in range(4)])
+    ys = np.concatenate([np.loadtxt(os.path.join(DS, f"si32_label{i}.txt")) for i in range(4)])
+    np.savez_compressed(os.path.join(HERE, "data_si128.npz"), X=Xs, y=ys)
+    Xq, yq = load_txt("sine_dataset_4096_10", 4096 + 64)      # 4096 train rows + 64 spare (test points)
+    np.savez_compressed(os.path.join(HERE, "data_sine_4160.npz"), X=Xq, y=yq)
+
+    # ---- si128: LL/grad/K/L/inverse/predict/NLPP/CG/BCM ----------------
+    g = {"dataset": "chunked_dataset/si32_chunk{0..3}.txt concatenated (= REF's input_128)", "cases": []}
+    for hp in (HP_BCM, HP_DEFAULT, HP_DENSE):
+        c = ll_grad(r, Xs, ys, hp)
+        K = r.K_train(Xs, hp)
+        L = r.cholesky(K)
+        Ki = r.K_inverse(K)
+        q, ld = r.chol_and_det(K, ys)
+        Xt = Xs[:3] * 0.9 + 0.05
+        m, v = r.predict(Xs, ys, hp, Xt)
+        c.update({"K_row5": K[5].tolist(), "K_diag": np.diag(K).tolist(), "L_row100": L[100].tolist(),
+                  "L_diag": np.diag(L).tolist(), "Kinv_row7": Ki[7].tolist(), "Kinv_trace": float(np.trace(Ki)),
+                  "quad": q, "logdet": ld, "Xt": Xt.tolist(), "pred_mean": m.tolist(), "pred_var": v.tolist(),
+                  "nlpp": r.nlpp(ys[:3], m, v)})
+        g["cases"].append(c)
+    # serial cg_solve from hp=1.5 (the REF run) and hp=0.5 (serial_gp.cpp default)
+    g["cg"] = []
+    for hp in (HP_BCM, HP_DEFAULT):
+        log = os.path.join(tmp, "cg.log")
+        final = r.cg_solve(Xs, ys, hp, log)
+        g["cg"].append({"hp0": list(hp), "final_hp": final.tolist(), "final_ll": r.loglik(Xs, ys, final),
+                        "please_see": parse_please_see(log)})
+    log = os.path.join(tmp, "rprop.log")
+    final = r.rprop_solve(Xs, ys, HP_BCM, log)
+    g["rprop"] = {"hp0": HP_BCM, "final_hp": final.tolist(), "final_ll": r.loglik(Xs, ys, final)}
+    # BCM, 4 experts x 32 rows (distributed_ver1.cpp:279-285)
+    b = r.bcm(Xs, ys, 4, HP_BCM)
+    log = os.path.join(tmp, "bcm_ll.log")
+    ll = b.loglik(log)
+    per = [float(m.group(1)) for m in re.finditer(r"LL of Expert \d+: ([-\d.]+)", open(log).read())]
+    Xt = np.vstack([Xs[:3], Xs[:5] * 0.7 - 0.1])
+    m, v = b.predict(Xt)
+    bc = {"K": 4, "hp": HP_BCM, "ll": ll, "ll_per_expert_6dp": per, "grad": b.grad().tolist(),
+          "Xt": Xt.tolist(), "pred_mean": m.tolist(), "pred_var": v.tolist(),
+          "nlpp": b.nlpp(np.concatenate([ys[:3], ys[:5]]), m, v)}
+    # uneven split: 3 experts over 128 rows -> 42,42,44 (BCM.cpp:92-108)
+    b3 = r.bcm(Xs, ys, 3, HP_DENSE)
+    m3, v3 = b3.predict(Xt)
+    bc["uneven"] = {"K": 3, "hp": HP_DENSE, "ll": b3.loglik(), "grad": b3.grad().tolist(),
+                    "pred_mean": m3.tolist(), "pred_var": v3.tolist()}
+    log = os.path.join(tmp, "bcm_cg.log")
+    b2 = r.bcm(Xs, ys, 4, HP_BCM)
+    final = b2.cg_solve(log)
+    bc["cg"] = {"hp0": HP_BCM, "final_hp": final.tolist(), "please_see": parse_please_see(log)}
+    g["bcm"] = bc
+    dump("golden_si128.json", g)
+
+    # ---- sine (D=10): 256 / 1024 / 2048 rows ----------------------------
+    s = {"dataset": "chunked_dataset/sine_dataset_4096_10_chunk0.txt, first n rows "
+                    "(the sine_dataset_{256,1024,2048}_10 files hold the same leading rows)", "cases": []}
+    X, y = Xq[:256], yq[:256]
+    for hp in (HP_DEFAULT, HP_DENSE):
+        c = ll_grad(r, X, y, hp)
+        Xt = Xq[4096:4096 + 8]
+        m, v = r.predict(X, y, hp, Xt)
+        c.update({"test_rows": [4096, 4104], "pred_mean": m.tolist(), "pred_var": v.tolist(),
+                  "nlpp": r.nlpp(yq[4096:4104], m, v)})
+        s["cases"].append(c)
+    log = os.path.join(tmp, "cg256.log")
+    final = r.cg_solve(X, y, HP_DENSE, log)
+    s["cg256"] = {"hp0": HP_DENSE, "final_hp": final.tolist(), "final_ll": r.loglik(X, y, final),
+                  "please_see": parse_please_see(log)}
+    b = r.bcm(Xq[:1024], yq[:1024], 4, HP_DENSE)
+    m, v = b.predict(Xq[4096:4104])
+    s["bcm1024x4"] = {"K": 4, "hp": HP_DENSE, "ll": b.loglik(), "grad": b.grad().tolist(),
+                      "test_rows": [4096, 4104], "pred_mean": m.tolist(), "pred_var": v.tolist()}
+    for n in (1024, 2048):
+        s["cases"].append(ll_grad(r, Xq[:n], yq[:n], HP_DENSE))
+        print("  n =", n, s["cases"][-1]["ll"], s["cases"][-1]["t_ll_s"], s["cases"][-1]["t_grad_s"])
+    dump("golden_sine.json", s)
+
+    # ---- the reference's committed run log (REF) ------------------------
+    refp = os.path.join(REF, "cuda_bettersinglenode_ver2", "REF")
+    txt = open(refp, errors="replace").read()
+    lls = [float(x) for x in re.findall(r"The value of loglikelihood = ([-\d.]+)", txt)]
+    grads = [[float(a), float(b_), float(c_)] for a, b_, c_ in
+             re.findall(r"Final gradients of log hyperparams are ([-\d.]+), ([-\d.]+), ([-\d.]+)", txt)]
+    ps = parse_please_see(refp)
+    dump("ref_log_si128.json", {"source": "cuda_bettersinglenode_ver2/REF (reference's committed stdout, 6 d.p.)",
+                                "hp0": HP_BCM, "loglik_values": lls, "gradients": grads, "please_see": ps})
+
+
+def big(r, n):
+    name = "golden_big_%d.json" % n          # one file per size: the two runs may overlap in time
+    path = os.path.join(HERE, name)
+    cur = {"cases": {}}
+    if n == 4096:
+        d = np.load(os.path.join(HERE, "data_sine_4160.npz"))
+        X, y, hp, key = d["X"][:4096], d["y"][:4096], HP_DENSE, "sine_4096"
+    elif n == 8192:
+        X, y = load_txt("siproper_9192_10")                 # 8192 train + 1000 test, ver2/main.cpp:178-181
+        np.savez_compressed(os.path.join(HERE, "data_siproper_9192.npz"), X=X, y=y)
+        X, y, hp, key = X[:8192], y[:8192], HP_DEFAULT, "siproper_8192"
+    else:
+        raise SystemExit("--big takes 4096 or 8192")
+    t0 = time.time()
+    ll = r.loglik(X, y, hp)
+    t1 = time.time()
+    cur["cases"][key] = {"hp": hp, "n": n, "ll": ll, "t_ll_s": round(t1 - t0, 2)}
+    dump(name, cur)
+    g = r.grad(X, y, hp)
+    t2 = time.time()
+    cur = json.load(open(path))
+    cur["cases"][key].update({"grad": g.tolist(), "t_grad_s": round(t2 - t1, 2)})
+    dump(name, cur)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--big", type=int, default=0)
+    a = ap.parse_args()
+    from oracle.oracle_py import Reference, build
+    build(ref=True)
+    ref = Reference()
+    if a.big:
+        big(ref, a.big)
+    else:
+        small(ref)
