@@ -131,9 +131,8 @@ int enqueue_potrf(cugp_gp* g)
     const int nt = g->nt, ld = g->npad;
     for (int kb = 0; kb < nt; kb++) {
         launch_potf2(g->dA, ld, kb, g->d16, g->dlogdet, s);
-        launch_trtri_diag(g->dA, ld, kb, 1, g->d16, g->dT, g->dU, s);
         if (kb + 1 < nt) {
-            launch_trsm_panel(g->dA, g->dT, ld, kb, nt, s);
+            launch_trsm_strips(g->dA, g->d16, ld, kb, nt, s);
             const bool ev = g->prof >= 2 && g->kev_used + 2 <= (int)g->kev.size();
             if (ev) HIPCHK(hipEventRecord(g->kev[g->kev_used], s));
             launch_syrk_trail(g->dA, ld, kb, nt, s);
@@ -145,6 +144,8 @@ int enqueue_potrf(cugp_gp* g)
             }
         }
     }
+    // inverses of all diagonal factor blocks at once (off the factorisation's critical path)
+    launch_trtri_diag(g->dA, ld, 0, nt, g->d16, g->dT, g->dU, s);
     HIPCHK(hipGetLastError());
     return CUGP_OK;
 }

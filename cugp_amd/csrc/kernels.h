@@ -23,7 +23,8 @@ void launch_kcross(const double* X, int n, int d, int npad, const double* Xt, in
 void launch_potf2(double* A, int ld, int kb, double* d16, double* logdet_part, hipStream_t s);
 void launch_trtri_diag(const double* A, int ld, int kb, int nblocks, const double* d16, double* T, double* U,
                        hipStream_t s);
-void launch_trsm_panel(double* A, const double* T, int ld, int kb, int nt, hipStream_t s);
+void launch_trsm_panel(double* A, const double* T, int ld, int kb, int nt, hipStream_t s);   // L21 = A21 T11^T (GEMM form)
+void launch_trsm_strips(double* A, const double* d16, int ld, int kb, int nt, hipStream_t s);   // block substitution
 void launch_syrk_trail(double* A, int ld, int kb, int nt, hipStream_t s);
 
 // ---- triangular inverse by recursive doubling (N7) and K^-1 = U U^T (N8) ----

@@ -394,118 +394,229 @@ __global__ __launch_bounds__(256) void k_cross(const double* __restrict__ X, int
 // ------------------------------------------------------------------------------------------
 // diagonal block: 128x128 Cholesky in LDS (one workgroup), 16-wide inner blocks
 // ------------------------------------------------------------------------------------------
-constexpr int PLD = TILE + 1;                      // padded LDS row stride (doubles)
-constexpr int POTF2_LDS = TILE * PLD * 8;          // 132096 B
+constexpr int PLD = TILE + 1;                      // padded LDS row stride (doubles) of k_trtri_diag
 constexpr int TRTRI_LDS = TILE * PLD * 8 + (TILE - 16) * 17 * 8;
 
+// ---- helpers for the diagonal block ------------------------------------------------------
+constexpr int MT = 16;                             // micro tile (one MFMA tile)
+constexpr int MTS = MT * (MT + 1);                 // doubles per LDS micro tile, rows padded to 17
+constexpr int NMT = TILE / MT;                     // 8 micro tiles per edge
+constexpr int NLT = NMT * (NMT + 1) / 2;           // 36 lower micro tiles
+constexpr int POTF2_LDS = (NLT * MTS + TILE) * 8;  // tiles + 1/L_ii  = 79360 B
+
+__device__ __forceinline__ int mt_off(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * MTS; }
+
+// broadcast of one lane's double through SGPRs (v_readlane x2); `src` must be wave-uniform
+__device__ __forceinline__ double readlane_f64(double v, int src)
+{
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u & 0xffffffffull), src);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), src);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+// 1/sqrt(x): v_rsq_f64 seed + two Newton steps; x <= 0 or NaN gives NaN/Inf that flows on
+__device__ __forceinline__ double rsqrt_nr(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        const double e = __builtin_fma(-x * y, y, 1.0);
+        y = __builtin_fma(0.5 * y, e, y);
+    }
+    return y;
+}
+
+// Cholesky of one 16x16 micro tile held in LDS (rows padded to 17), by ONE wave: lane l owns row
+// l & 15 in registers, right-looking, pivots and column factors broadcast with v_readlane.
+// Writes the factor back (upper zeroed) and 1/L_cc into rinv[0..15].
+__device__ __forceinline__ void micro_factor(double* __restrict__ tile, double* __restrict__ rinv)
+{
+    const int lane = threadIdx.x & 63, i = lane & 15;
+    double r[MT];
+#pragma unroll
+    for (int c = 0; c < MT; c++) r[c] = tile[i * (MT + 1) + c];
+#pragma unroll
+    for (int c = 0; c < MT; c++) {
+        const double piv = readlane_f64(r[c], c);
+        const double rs = rsqrt_nr(piv);
+        const double lc = r[c] * rs;
+        r[c] = lc;
+        if (lane == c) rinv[c] = rs;
+#pragma unroll
+        for (int c2 = c + 1; c2 < MT; c2++) {
+            const double o = readlane_f64(lc, c2);
+            r[c2] = __builtin_fma(-lc, o, r[c2]);
+        }
+    }
+    if (lane < MT) {
+#pragma unroll
+        for (int c = 0; c < MT; c++) tile[i * (MT + 1) + c] = (c <= i) ? r[c] : 0.0;
+    }
+}
+
+// C(bi,bj) -= X(bi,jb) * X(bj,jb)^T on LDS micro tiles, one wave, 4 MFMAs
+__device__ __forceinline__ void micro_update(double* __restrict__ sm, int bi, int bj, int jb)
+{
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    double* C = sm + mt_off(bi, bj);
+    const double* Xi = sm + mt_off(bi, jb);
+    const double* Xj = sm + mt_off(bj, jb);
+    d4 acc;
+#pragma unroll
+    for (int r = 0; r < 4; r++) acc[r] = C[(g + 4 * r) * (MT + 1) + c];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const double a = -Xi[c * (MT + 1) + 4 * s + g];
+        const double b = Xj[c * (MT + 1) + 4 * s + g];
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) C[(g + 4 * r) * (MT + 1) + c] = acc[r];
+}
+
+// ------------------------------------------------------------------------------------------
+// diagonal block: 128x128 Cholesky by one workgroup.  The lower triangle lives in LDS as 36
+// padded 16x16 micro tiles (78 KiB: fits beside one resident MFMA workgroup on the CU).
+// Per 16-wide inner step: (A) micro_factor of the diagonal micro tile in registers (one wave),
+// (B) the rows below by per-row forward substitution (L_jj broadcast from LDS), (C) rank-16
+// update of the remaining micro tiles with MFMA -- wave 0 takes the next diagonal tile first and
+// factors it while waves 1..3 finish the update (look-ahead inside the block).
+// Outputs: L (lower) back into A, the 16x16 diagonal inverses (d16, used by the panel solve and
+// the inverse), and this block's share of log|K|.
+// ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_potf2(double* __restrict__ A, int ld, int kb, double* __restrict__ d16,
                                                double* __restrict__ logdet_part)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    __shared__ double dinv[16][17];
+    double* rinv = sm + NLT * MTS;                          // 1 / L_ii, 128 entries
     __shared__ double red[TILE];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     double* Ab = A + (size_t)kb * TILE * ld + kb * TILE;
 
-    for (int e = t; e < TILE * TILE; e += 256) {
-        int r = e >> 7, c = e & 127;
-        sm[r * PLD + c] = (c <= r) ? Ab[(size_t)r * ld + c] : 0.0;
+    {   // load the lower micro tiles; thread t = element (t>>4, t&15) of every tile
+        const int r = t >> 4, c = t & 15;
+        for (int bi = 0; bi < NMT; bi++)
+            for (int bj = 0; bj <= bi; bj++)
+                sm[mt_off(bi, bj) + r * (MT + 1) + c] = Ab[(size_t)(bi * MT + r) * ld + bj * MT + c];
     }
     __syncthreads();
+    if (wave == 0) micro_factor(sm + mt_off(0, 0), rinv);
+    __syncthreads();
 
-    for (int jb = 0; jb < TILE / 16; jb++) {
-        const int j0 = jb * 16;
-        if (wave == 0) {
-            // lane l (< 16) owns row l of the 16x16 diagonal block; lanes >= 16 mirror lane l & 15
-            const int l = lane & 15;
-            double r[16];
+    for (int jb = 0; jb < NMT - 1; jb++) {
+        const int m = NMT - 1 - jb;                         // micro tiles below the diagonal one
+        // (B) rows below: x_c = (a_c - sum_{k<c} x_k L_ck) / L_cc
+        if (t < m * MT) {
+            const int bi = jb + 1 + (t >> 4), r = t & 15;
+            double* row = sm + mt_off(bi, jb) + r * (MT + 1);
+            const double* Ljj = sm + mt_off(jb, jb);
+            double x[MT];
 #pragma unroll
-            for (int c = 0; c < 16; c++) r[c] = sm[(j0 + l) * PLD + j0 + c];
+            for (int c = 0; c < MT; c++) {
+                double sacc = row[c];
 #pragma unroll
-            for (int c = 0; c < 16; c++) {
-                const double piv = __shfl(r[c], c, 64);
-                const double dg = sqrt(piv);                 // non-PD => NaN, flows on (never traps)
-                const double lc = (l == c) ? dg : r[c] / dg;
-                r[c] = lc;
-#pragma unroll
-                for (int c2 = c + 1; c2 < 16; c2++) {
-                    const double o = __shfl(lc, c2, 64);
-                    r[c2] -= lc * o;
-                }
+                for (int k = 0; k < c; k++) sacc = __builtin_fma(-x[k], Ljj[c * (MT + 1) + k], sacc);
+                x[c] = sacc * rinv[jb * MT + c];
             }
-            // inverse of the 16x16 factor: lane j builds column j of Tinv by forward substitution
-            double tc[16];
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                double s = (i == l) ? 1.0 : 0.0;
-#pragma unroll
-                for (int k = 0; k < i; k++) {
-                    const double lik = __shfl(r[k], i, 64);
-                    s -= lik * tc[k];
-                }
-                const double lii = __shfl(r[i], i, 64);
-                tc[i] = s / lii;
-            }
-            if (lane < 16) {
-#pragma unroll
-                for (int c = 0; c < 16; c++) sm[(j0 + l) * PLD + j0 + c] = (c <= l) ? r[c] : 0.0;
-#pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    dinv[i][l] = tc[i];
-                    d16[((size_t)kb * 8 + jb) * 256 + i * 16 + l] = tc[i];
-                }
-            }
+            for (int c = 0; c < MT; c++) row[c] = x[c];
         }
         __syncthreads();
-        const int m = TILE - j0 - 16;                         // rows below the diagonal block
-        if (m > 0) {
-            // panel: X[i][c] = sum_{k<=c} A[i][j0+k] * Dinv[c][k]
-            double xs[7];
+        // (C) trailing micro tiles of this 128 block
+        if (wave == 0) {
+            micro_update(sm, jb + 1, jb + 1, jb);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            micro_factor(sm + mt_off(jb + 1, jb + 1), rinv + (jb + 1) * MT);
+        } else {
+            int n = 0;                                      // column jb+1 first, then the rest
+            for (int bi = jb + 2; bi < NMT; bi++, n++)
+                if (n % 3 == wave - 1) micro_update(sm, bi, jb + 1, jb);
+            for (int bj = jb + 2; bj < NMT; bj++)
+                for (int bi = bj; bi < NMT; bi++, n++)
+                    if (n % 3 == wave - 1) micro_update(sm, bi, bj, jb);
+        }
+        __syncthreads();
+    }
+
+    {   // factor back to global (lower micro tiles; diagonal tiles carry zeros above the diagonal)
+        const int r = t >> 4, c = t & 15;
+        for (int bi = 0; bi < NMT; bi++)
+            for (int bj = 0; bj <= bi; bj++)
+                Ab[(size_t)(bi * MT + r) * ld + bj * MT + c] = sm[mt_off(bi, bj) + r * (MT + 1) + c];
+    }
+    // inverses of the 16x16 diagonal factors: lane j builds column j by forward substitution
+    for (int jb = wave; jb < NMT; jb += 4) {
+        const int j = lane & 15;
+        const double* Ljj = sm + mt_off(jb, jb);
+        double tc[MT];
 #pragma unroll
-            for (int q = 0; q < 7; q++) {
-                const int e = t + 256 * q;
-                double sacc = 0.0;
-                if (e < m * 16) {
-                    const int i = j0 + 16 + (e >> 4), c = e & 15;
-                    for (int k = 0; k <= c; k++) sacc += sm[i * PLD + j0 + k] * dinv[c][k];
-                }
-                xs[q] = sacc;
-            }
-            __syncthreads();
+        for (int i = 0; i < MT; i++) {
+            double sacc = (i == j) ? 1.0 : 0.0;
 #pragma unroll
-            for (int q = 0; q < 7; q++) {
-                const int e = t + 256 * q;
-                if (e < m * 16) {
-                    const int i = j0 + 16 + (e >> 4), c = e & 15;
-                    sm[i * PLD + j0 + c] = xs[q];
-                }
-            }
-            __syncthreads();
-            // trailing update of the lower triangle: A[i][c] -= sum_k X[i][k] X[c][k]
-            for (int e = t; e < m * m; e += 256) {
-                const int i = j0 + 16 + e / m, c = j0 + 16 + e % m;
-                if (c <= i) {
-                    double s = 0.0;
+            for (int k = 0; k < i; k++) sacc = __builtin_fma(-Ljj[i * (MT + 1) + k], tc[k], sacc);
+            tc[i] = sacc * rinv[jb * MT + i];
+        }
+        if (lane < MT) {
+            double* dst = d16 + ((size_t)kb * NMT + jb) * (MT * MT);
 #pragma unroll
-                    for (int k = 0; k < 16; k++) s += sm[i * PLD + j0 + k] * sm[c * PLD + j0 + k];
-                    sm[i * PLD + c] -= s;
-                }
-            }
-            __syncthreads();
+            for (int i = 0; i < MT; i++) dst[i * MT + j] = tc[i];
         }
     }
-    for (int e = t; e < TILE * TILE; e += 256) {
-        int r = e >> 7, c = e & 127;
-        if (c <= r) Ab[(size_t)r * ld + c] = sm[r * PLD + c];
-    }
-    // log-determinant share of this block, summed in a fixed order
-    if (t < TILE) red[t] = log(sm[t * PLD + t]);
+    // log-determinant share of this block, summed in a fixed order: log L_ii = -log(1/L_ii)
+    if (t < TILE) red[t] = -log(rinv[t]);
     __syncthreads();
     for (int w = TILE / 2; w > 0; w >>= 1) {
         if (t < w) red[t] += red[t + w];
         __syncthreads();
     }
     if (t == 0) logdet_part[kb] = red[0];
+}
+
+// ------------------------------------------------------------------------------------------
+// panel solve L21 = A21 L11^-T by block substitution on 16-row strips, ONE WAVE per strip, no LDS:
+//   X_j^T = D_j ( A_j^T - sum_{k<j} L_jk X_k^T ),  j = 0..7   (D_j = inverse of the 16x16 diagonal factor)
+// Everything is kept transposed so an MFMA result (C/D layout) is directly the B operand of the
+// next MFMA with the k index mapped as k = (lane>>4) + 4*reg; the A operands (L_jk, D_j) are read
+// from global/L2 with the same map.  144 MFMAs per strip, strips are independent.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_trsm_strips(double* __restrict__ A, const double* __restrict__ d16,
+                                                     int ld, int kb, int nstrips)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int strip = blockIdx.x * 4 + wave;
+    if (strip >= nstrips) return;
+    const int k0 = kb * TILE;
+    const int c = lane & 15, g = lane >> 4;
+    double* Arow = A + (size_t)(k0 + TILE + strip * MT + c) * ld + k0;     // my row of the strip
+    const double* L = A + (size_t)k0 * ld + k0;                             // diagonal factor block
+    const double* D = d16 + (size_t)kb * NMT * (MT * MT);
+    d4 X[NMT];
+#pragma unroll
+    for (int j = 0; j < NMT; j++) {
+        d4 z;
+#pragma unroll
+        for (int r = 0; r < 4; r++) z[r] = Arow[j * MT + g + 4 * r];
+#pragma unroll
+        for (int k = 0; k < NMT; k++) {
+            if (k < j) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const double a = -L[(size_t)(j * MT + c) * ld + k * MT + g + 4 * r];
+                    z = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[k][r], z, 0, 0, 0);
+                }
+            }
+        }
+        d4 y = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const double a = D[j * (MT * MT) + c * MT + g + 4 * r];
+            y = __builtin_amdgcn_mfma_f64_16x16x4f64(a, z[r], y, 0, 0, 0);
+        }
+        X[j] = y;
+#pragma unroll
+        for (int r = 0; r < 4; r++) Arow[j * MT + g + 4 * r] = y[r];
+    }
 }
 
 // inverse of a 128x128 diagonal factor block from its 16x16 diagonal inverses (blocked, right to left);
@@ -786,6 +897,13 @@ void launch_trsm_panel(double* A, const double* T, int ld, int kb, int nt, hipSt
     const int m = nt - kb - 1;
     if (m <= 0) return;
     hipLaunchKernelGGL(k_trsm_panel, dim3(m), dim3(256), 0, s, A, T, ld, kb);
+}
+
+void launch_trsm_strips(double* A, const double* d16, int ld, int kb, int nt, hipStream_t s)
+{
+    const int nstrips = (nt - kb - 1) * (TILE / MT);
+    if (nstrips <= 0) return;
+    hipLaunchKernelGGL(k_trsm_strips, dim3((nstrips + 3) / 4), dim3(256), 0, s, A, d16, ld, kb, nstrips);
 }
 
 void launch_syrk_trail(double* A, int ld, int kb, int nt, hipStream_t s)
