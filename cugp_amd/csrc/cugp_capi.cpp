@@ -50,7 +50,9 @@ constexpr int MAX_KEV = 4096;   // per-launch event pairs kept between resets
 
 struct cugp_gp {
     int n = 0, d = 0, npad = 0, nt = 0, device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;   // main stream: everything is ordered here ...
+    hipStream_t chain = nullptr;    // ... except the diagonal-block chain of the factorisation (high priority)
+    std::vector<hipEvent_t> ev_p, ev_r;   // P[k]: diagonal block k factored; R[k]: panel k solved (R[nt]: inputs ready)
     double *dX = nullptr, *dy = nullptr, *dA = nullptr, *dT = nullptr, *dU = nullptr, *dKinv = nullptr;
     double *dz = nullptr, *dalpha = nullptr, *dw = nullptr, *d16 = nullptr, *dlogdet = nullptr, *dpart = nullptr;
     double* dout = nullptr;
@@ -124,28 +126,41 @@ void drain_kernel_events(cugp_gp* g)
     g->kev_used = 0;
 }
 
-// blocked right-looking Cholesky of A (lower), diagonal-block inverses into T/U's diagonal tiles
+// Blocked right-looking Cholesky of A (lower) with depth-1 look-ahead on two HIP streams:
+//   chain (high priority): [update of the NEXT diagonal tile] -> potf2 of it           -> P[k+1]
+//   main                 : wait P[k] -> panel solve(k) -> R[k] -> trailing update(k) without that tile
+// so the latency-bound diagonal block of step k+1 runs beside the MFMA-bound trailing update of step k.
 int enqueue_potrf(cugp_gp* g)
 {
-    hipStream_t s = g->stream;
+    hipStream_t m = g->stream, c = g->chain;
     const int nt = g->nt, ld = g->npad;
-    for (int kb = 0; kb < nt; kb++) {
-        launch_potf2(g->dA, ld, kb, g->d16, g->dlogdet, s);
-        if (kb + 1 < nt) {
-            launch_trsm_strips(g->dA, g->d16, ld, kb, nt, s);
+    HIPCHK(hipEventRecord(g->ev_r[nt], m));                 // everything before (kernel build / upload)
+    HIPCHK(hipStreamWaitEvent(c, g->ev_r[nt], 0));
+    launch_potf2(g->dA, ld, 0, g->d16, g->dlogdet, c);
+    HIPCHK(hipEventRecord(g->ev_p[0], c));
+    for (int kb = 0; kb + 1 < nt; kb++) {
+        HIPCHK(hipStreamWaitEvent(m, g->ev_p[kb], 0));
+        launch_trsm_strips(g->dA, g->d16, ld, kb, nt, m);
+        HIPCHK(hipEventRecord(g->ev_r[kb], m));
+        HIPCHK(hipStreamWaitEvent(c, g->ev_r[kb], 0));
+        launch_syrk_diag(g->dA, ld, kb, c);
+        launch_potf2(g->dA, ld, kb + 1, g->d16, g->dlogdet, c);
+        HIPCHK(hipEventRecord(g->ev_p[kb + 1], c));
+        if (nt - kb - 1 > 1) {
             const bool ev = g->prof >= 2 && g->kev_used + 2 <= (int)g->kev.size();
-            if (ev) HIPCHK(hipEventRecord(g->kev[g->kev_used], s));
-            launch_syrk_trail(g->dA, ld, kb, nt, s);
+            if (ev) HIPCHK(hipEventRecord(g->kev[g->kev_used], m));
+            launch_syrk_trail(g->dA, ld, kb, nt, true, m);
             if (ev) {
-                HIPCHK(hipEventRecord(g->kev[g->kev_used + 1], s));
+                HIPCHK(hipEventRecord(g->kev[g->kev_used + 1], m));
                 g->kev_used += 2;
-                const double m = (double)(nt - kb - 1) * TILE;
-                g->kev_flop += m * m * TILE;            // lower triangle only: m^2 * nb (mul+add)
+                const double me = (double)(nt - kb - 1) * TILE;
+                g->kev_flop += (me * me - (double)TILE * TILE) * TILE;   // lower triangle, mul+add, minus the diag tile
             }
         }
     }
+    HIPCHK(hipStreamWaitEvent(m, g->ev_p[nt - 1], 0));
     // inverses of all diagonal factor blocks at once (off the factorisation's critical path)
-    launch_trtri_diag(g->dA, ld, 0, nt, g->d16, g->dT, g->dU, s);
+    launch_trtri_diag(g->dA, ld, 0, nt, g->d16, g->dT, g->dU, m);
     HIPCHK(hipGetLastError());
     return CUGP_OK;
 }
@@ -261,6 +276,17 @@ int cugp_create(int n, int d, int device, cugp_gp** out)
     *out = nullptr;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        e = hipStreamCreateWithPriority(&g->chain, hipStreamNonBlocking, hi);
+    }
+    g->ev_p.assign(g->nt + 1, nullptr);
+    g->ev_r.assign(g->nt + 1, nullptr);
+    for (int i = 0; i <= g->nt && e == hipSuccess; i++) {
+        e = hipEventCreateWithFlags(&g->ev_p[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_r[i], hipEventDisableTiming);
+    }
     if (e == hipSuccess) e = hipMalloc((void**)&g->dX, (size_t)n * d * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&g->dy, (size_t)g->npad * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&g->dz, (size_t)g->npad * sizeof(double));
@@ -286,6 +312,7 @@ int cugp_destroy(cugp_gp* g)
     if (!g) return CUGP_OK;
     (void)hipSetDevice(g->device);
     if (g->stream) (void)hipStreamSynchronize(g->stream);
+    if (g->chain) (void)hipStreamSynchronize(g->chain);
     double* bufs[] = {g->dX, g->dy, g->dA, g->dT, g->dU, g->dKinv, g->dz, g->dalpha, g->dw, g->d16, g->dlogdet,
                       g->dpart, g->dout};
     for (double* p : bufs)
@@ -294,6 +321,9 @@ int cugp_destroy(cugp_gp* g)
     for (int i = 0; i <= NPHASE; i++)
         if (g->pev[i]) (void)hipEventDestroy(g->pev[i]);
     for (hipEvent_t e : g->kev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : g->ev_p) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : g->ev_r) if (e) (void)hipEventDestroy(e);
+    if (g->chain) (void)hipStreamDestroy(g->chain);
     if (g->stream) (void)hipStreamDestroy(g->stream);
     delete g;
     return CUGP_OK;

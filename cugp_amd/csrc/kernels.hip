@@ -40,8 +40,18 @@ constexpr int GEMM_LDS = 2 * STAGE;          // double buffered: 64 KiB
 
 __device__ __forceinline__ int lds_slot(int row, int plane) { return ((row + plane) & (TILE - 1)) * 16; }
 
-// acc[m][n] += A(i0.., kbeg..kend) * B(j0.., kbeg..kend)^T ; Ag -> A[i0][0], Bg -> B[j0][0];
+// B-operand rows are stored permuted inside each 64-row half so that MFMA tiles n = 2p, 2p+1 of a
+// wave produce ADJACENT output columns in one lane (16-byte global accesses in the epilogue) while
+// the fragment reads stay 256 contiguous bytes: tile row R -> LDS position bpos(R).
+__device__ __forceinline__ int bpos(int R)
+{
+    const int h = R & 64, q = R & 63;
+    return h + (((q >> 5) * 2 + (q & 1)) * 16) + ((q & 31) >> 1);
+}
+
+// acc[m][n] += (NEGA ? -1 : 1) * A(i0.., kbeg..kend) * B(j0.., kbeg..kend)^T ; Ag -> A[i0][0], Bg -> B[j0][0];
 // kbeg, kend multiples of BK.  All 256 threads must call (barriers inside).
+template <bool NEGA>
 __device__ __forceinline__ void tile_nt(const double* __restrict__ Ag, int lda, const double* __restrict__ Bg,
                                         int ldb, int kbeg, int kend, d4 (&acc)[4][4], char* smem)
 {
@@ -54,6 +64,12 @@ __device__ __forceinline__ void tile_nt(const double* __restrict__ Ag, int lda, 
     const double* ag = Ag + (size_t)srow * lda + 2 * skp;
     const double* bg = Bg + (size_t)srow * ldb + 2 * skp;
     d2 ra[4], rb[4];
+    int wa[4], wb[4];                                     // LDS byte offsets of my staging chunks
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        wa[q] = skp * PLANE + lds_slot(srow + 32 * q, skp);
+        wb[q] = OPER + skp * PLANE + lds_slot(bpos(srow + 32 * q), skp);
+    }
 
     const int nk = (kend - kbeg) / BK;
     if (nk <= 0) return;
@@ -65,9 +81,8 @@ __device__ __forceinline__ void tile_nt(const double* __restrict__ Ag, int lda, 
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        int row = srow + 32 * q;
-        *(d2*)(smem + skp * PLANE + lds_slot(row, skp)) = ra[q];
-        *(d2*)(smem + OPER + skp * PLANE + lds_slot(row, skp)) = rb[q];
+        *(d2*)(smem + wa[q]) = NEGA ? -ra[q] : ra[q];
+        *(d2*)(smem + wb[q]) = rb[q];
     }
     __syncthreads();
 
@@ -104,9 +119,8 @@ __device__ __forceinline__ void tile_nt(const double* __restrict__ Ag, int lda, 
         if (more) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                int row = srow + 32 * q;
-                *(d2*)(nxt + skp * PLANE + lds_slot(row, skp)) = ra[q];
-                *(d2*)(nxt + OPER + skp * PLANE + lds_slot(row, skp)) = rb[q];
+                *(d2*)(nxt + wa[q]) = NEGA ? -ra[q] : ra[q];
+                *(d2*)(nxt + wb[q]) = rb[q];
             }
         }
         __syncthreads();
@@ -121,14 +135,14 @@ __device__ __forceinline__ void acc_zero(d4 (&acc)[4][4])
         for (int n = 0; n < 4; n++) acc[m][n] = (d4){0.0, 0.0, 0.0, 0.0};
 }
 
-// accumulator element (m,n,r) of this lane is C[row][col] with (f64 16x16x4 C/D map:
-// col = lane&15, row = (lane>>4) + 4*r inside each 16x16 tile)
+// accumulator element (m,n,r) of this lane is C[row][col]: f64 16x16x4 C/D map (col = lane&15,
+// row = (lane>>4) + 4*r inside a 16x16 tile) composed with the B-row permutation above, so tiles
+// n = 2p and 2p+1 hold columns 2*(lane&15) and 2*(lane&15)+1 of the 32-column group p.
 #define ACC_ROW(m, r) (wr * 64 + (m) * 16 + (lane >> 4) + 4 * (r))
-#define ACC_COL(n) (wc * 64 + (n) * 16 + (lane & 15))
+#define ACC_COL2(np) (wc * 64 + (np) * 32 + 2 * (lane & 15))
 
-// C = alpha*acc + beta*C
-__device__ __forceinline__ void tile_store(double* __restrict__ C, int ldc, const d4 (&acc)[4][4], double alpha,
-                                           double beta)
+// acc = C   (the K loop then accumulates straight onto it: no read-modify-write epilogue)
+__device__ __forceinline__ void tile_load(const double* __restrict__ C, int ldc, d4 (&acc)[4][4])
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -137,12 +151,26 @@ __device__ __forceinline__ void tile_store(double* __restrict__ C, int ldc, cons
 #pragma unroll
         for (int r = 0; r < 4; r++)
 #pragma unroll
-            for (int n = 0; n < 4; n++) {
-                double* p = C + (size_t)ACC_ROW(m, r) * ldc + ACC_COL(n);
-                double v = alpha * acc[m][n][r];
-                if (beta != 0.0) v += beta * (*p);
-                *p = v;
+            for (int np = 0; np < 2; np++) {
+                const d2 v = *(const d2*)(C + (size_t)ACC_ROW(m, r) * ldc + ACC_COL2(np));
+                acc[m][2 * np][r] = v[0];
+                acc[m][2 * np + 1][r] = v[1];
             }
+}
+
+// C = alpha * acc
+__device__ __forceinline__ void tile_store(double* __restrict__ C, int ldc, const d4 (&acc)[4][4], double alpha)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int np = 0; np < 2; np++)
+                *(d2*)(C + (size_t)ACC_ROW(m, r) * ldc + ACC_COL2(np)) =
+                    (d2){alpha * acc[m][2 * np][r], alpha * acc[m][2 * np + 1][r]};
 }
 
 // Ct[col][row] = alpha*acc  (transposed store)
@@ -156,7 +184,7 @@ __device__ __forceinline__ void tile_store_t(double* __restrict__ Ct, int ldc, c
         for (int n = 0; n < 4; n++)
 #pragma unroll
             for (int r = 0; r < 4; r++)
-                Ct[(size_t)ACC_COL(n) * ldc + ACC_ROW(m, r)] = alpha * acc[m][n][r];
+                Ct[(size_t)(ACC_COL2(n >> 1) + (n & 1)) * ldc + ACC_ROW(m, r)] = alpha * acc[m][n][r];
 }
 
 // lower-triangular tile index: idx -> (ti >= tj)
@@ -179,22 +207,22 @@ __global__ __launch_bounds__(256, 2) void k_trsm_panel(double* __restrict__ A, c
     d4 acc[4][4];
     acc_zero(acc);
     // whole 128-deep k range is read into LDS before the first store, so in place is safe
-    tile_nt(A + (size_t)i0 * ld + k0, ld, T + (size_t)k0 * ld + k0, ld, 0, TILE, acc, smem);
-    tile_store(A + (size_t)i0 * ld + k0, ld, acc, 1.0, 0.0);
+    tile_nt<false>(A + (size_t)i0 * ld + k0, ld, T + (size_t)k0 * ld + k0, ld, 0, TILE, acc, smem);
+    tile_store(A + (size_t)i0 * ld + k0, ld, acc, 1.0);
 }
 
 // ---- Cholesky trailing update: A22(lower tiles) -= L21 * L21^T ----
-__global__ __launch_bounds__(256, 2) void k_syrk_trail(double* __restrict__ A, int ld, int kb)
+__global__ __launch_bounds__(256, 2) void k_syrk_trail(double* __restrict__ A, int ld, int kb, int first)
 {
     __shared__ __attribute__((aligned(16))) char smem[GEMM_LDS];
     int ti, tj;
-    tri_index(blockIdx.x, ti, tj);
+    tri_index(blockIdx.x + first, ti, tj);
     const int k0 = kb * TILE;
     const int i0 = (kb + 1 + ti) * TILE, j0 = (kb + 1 + tj) * TILE;
     d4 acc[4][4];
-    acc_zero(acc);
-    tile_nt(A + (size_t)i0 * ld + k0, ld, A + (size_t)j0 * ld + k0, ld, 0, TILE, acc, smem);
-    tile_store(A + (size_t)i0 * ld + j0, ld, acc, -1.0, 1.0);
+    tile_load(A + (size_t)i0 * ld + j0, ld, acc);
+    tile_nt<true>(A + (size_t)i0 * ld + k0, ld, A + (size_t)j0 * ld + k0, ld, 0, TILE, acc, smem);
+    tile_store(A + (size_t)i0 * ld + j0, ld, acc, 1.0);
 }
 
 // ---- K^-1 (lower tiles, diagonal tiles complete) = U * U^T, U = L^-T upper ----
@@ -206,8 +234,8 @@ __global__ __launch_bounds__(256, 2) void k_lauum(const double* __restrict__ U, 
     tri_index(blockIdx.x, ti, tj);       // ascending ti = longest k ranges first
     d4 acc[4][4];
     acc_zero(acc);
-    tile_nt(U + (size_t)ti * TILE * ld, ld, U + (size_t)tj * TILE * ld, ld, ti * TILE, nt * TILE, acc, smem);
-    tile_store(Kinv + (size_t)ti * TILE * ld + tj * TILE, ld, acc, 1.0, 0.0);
+    tile_nt<false>(U + (size_t)ti * TILE * ld, ld, U + (size_t)tj * TILE * ld, ld, ti * TILE, nt * TILE, acc, smem);
+    tile_store(Kinv + (size_t)ti * TILE * ld + tj * TILE, ld, acc, 1.0);
 }
 
 // ---- recursive-doubling inverse, one level.  Blocks of s tiles: [A 0; C B]^-1 = [TA 0; -TB C TA, TB].
@@ -230,13 +258,14 @@ __global__ __launch_bounds__(256, 2) void k_trtri_level(const double* __restrict
     d4 acc[4][4];
     acc_zero(acc);
     if (step == 1) {
-        tile_nt(U + (size_t)tj * TILE * ld, ld, L + (size_t)ti * TILE * ld, ld, tj * TILE, b0 * TILE, acc, smem);
-        tile_store(T + (size_t)tj * TILE * ld + ti * TILE, ld, acc, 1.0, 0.0);
+        tile_nt<false>(U + (size_t)tj * TILE * ld, ld, L + (size_t)ti * TILE * ld, ld, tj * TILE, b0 * TILE, acc,
+                       smem);
+        tile_store(T + (size_t)tj * TILE * ld + ti * TILE, ld, acc, 1.0);
     } else {
-        tile_nt(T + (size_t)ti * TILE * ld, ld, T + (size_t)tj * TILE * ld, ld, b0 * TILE, (ti + 1) * TILE, acc,
-                smem);
-        tile_store(T + (size_t)ti * TILE * ld + tj * TILE, ld, acc, -1.0, 0.0);
-        tile_store_t(U + (size_t)tj * TILE * ld + ti * TILE, ld, acc, -1.0);
+        tile_nt<true>(T + (size_t)ti * TILE * ld, ld, T + (size_t)tj * TILE * ld, ld, b0 * TILE, (ti + 1) * TILE,
+                      acc, smem);
+        tile_store(T + (size_t)ti * TILE * ld + tj * TILE, ld, acc, 1.0);
+        tile_store_t(U + (size_t)tj * TILE * ld + ti * TILE, ld, acc, 1.0);
     }
 }
 
@@ -248,8 +277,8 @@ __global__ __launch_bounds__(256, 2) void k_predict_gemm(const double* __restric
     const int tt = blockIdx.x % ntt, ti = blockIdx.x / ntt;
     d4 acc[4][4];
     acc_zero(acc);
-    tile_nt(Ks + (size_t)tt * TILE * ld, ld, T + (size_t)ti * TILE * ld, ld, 0, (ti + 1) * TILE, acc, smem);
-    tile_store(W + (size_t)tt * TILE * ld + ti * TILE, ld, acc, 1.0, 0.0);
+    tile_nt<false>(Ks + (size_t)tt * TILE * ld, ld, T + (size_t)ti * TILE * ld, ld, 0, (ti + 1) * TILE, acc, smem);
+    tile_store(W + (size_t)tt * TILE * ld + ti * TILE, ld, acc, 1.0);
 }
 
 // ---- plain NT product for tests ----
@@ -260,8 +289,8 @@ __global__ __launch_bounds__(256, 2) void k_test_gemm(const double* __restrict__
     const int ti = blockIdx.x % mt, tj = blockIdx.x / mt;
     d4 acc[4][4];
     acc_zero(acc);
-    tile_nt(A + (size_t)ti * TILE * k, k, B + (size_t)tj * TILE * k, k, 0, k, acc, smem);
-    tile_store(C + (size_t)ti * TILE * n + tj * TILE, n, acc, 1.0, 0.0);
+    tile_nt<false>(A + (size_t)ti * TILE * k, k, B + (size_t)tj * TILE * k, k, 0, k, acc, smem);
+    tile_store(C + (size_t)ti * TILE * n + tj * TILE, n, acc, 1.0);
 }
 
 __global__ __launch_bounds__(256) void k_mfma_peak(double* sink, int iters)
@@ -571,6 +600,29 @@ __global__ __launch_bounds__(256) void k_potf2(double* __restrict__ A, int ld, i
         __syncthreads();
     }
     if (t == 0) logdet_part[kb] = red[0];
+}
+
+// next diagonal tile only: A(kb+1,kb+1) -= L(kb+1,kb) L(kb+1,kb)^T, one WAVE per 16x16 micro tile (36 waves),
+// operands straight from L2 -- the short kernel that lets the next diagonal block start while the big
+// trailing update is still running on the other stream
+__global__ __launch_bounds__(256) void k_syrk_diag(double* __restrict__ A, int ld, int kb)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int bi, bj;
+    tri_index(blockIdx.x * 4 + wave, bi, bj);
+    const int c = lane & 15, g = lane >> 4;
+    const int k0 = kb * TILE, i0 = (kb + 1) * TILE;
+    const double* Li = A + (size_t)(i0 + bi * MT + c) * ld + k0 + g;
+    const double* Lj = A + (size_t)(i0 + bj * MT + c) * ld + k0 + g;
+    double* C = A + (size_t)(i0 + bi * MT + g) * ld + i0 + bj * MT + c;
+    d4 acc;
+#pragma unroll
+    for (int r = 0; r < 4; r++) acc[r] = C[(size_t)(4 * r) * ld];
+#pragma unroll 8
+    for (int s = 0; s < TILE / 4; s++)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Li[4 * s], Lj[4 * s], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; r++) C[(size_t)(4 * r) * ld] = acc[r];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -906,11 +958,17 @@ void launch_trsm_strips(double* A, const double* d16, int ld, int kb, int nt, hi
     hipLaunchKernelGGL(k_trsm_strips, dim3((nstrips + 3) / 4), dim3(256), 0, s, A, d16, ld, kb, nstrips);
 }
 
-void launch_syrk_trail(double* A, int ld, int kb, int nt, hipStream_t s)
+void launch_syrk_trail(double* A, int ld, int kb, int nt, bool skip_next_diag, hipStream_t s)
 {
     const int m = nt - kb - 1;
-    if (m <= 0) return;
-    hipLaunchKernelGGL(k_syrk_trail, dim3(tri_count(m)), dim3(256), 0, s, A, ld, kb);
+    const int first = skip_next_diag ? 1 : 0;          // tile 0 = (kb+1, kb+1), done by launch_syrk_diag
+    if (tri_count(m) - first <= 0) return;
+    hipLaunchKernelGGL(k_syrk_trail, dim3(tri_count(m) - first), dim3(256), 0, s, A, ld, kb, first);
+}
+
+void launch_syrk_diag(double* A, int ld, int kb, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_syrk_diag, dim3(NLT / 4), dim3(256), 0, s, A, ld, kb);
 }
 
 void launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, int s, int step, hipStream_t st)
