@@ -1,0 +1,122 @@
+"""Product-of-experts ("BCM") sharded one process per GPU.
+
+The reference shards experts over worker processes -- chunk i goes to worker i mod W
+(cuda_scalingdist/cg_solver.cpp:93,166; main.cpp:101,156) -- and moves 1 (log-likelihood) or 3
+(gradient) doubles per worker over TCP for every evaluation (cg_solver.cpp:72-213), plus a 3-double
+hyper-parameter broadcast (:245-279).  Here every rank keeps its experts resident on its GPU, runs the
+same deterministic host optimiser, and one all-reduce per evaluation carries the per-expert
+[LL, g0, g1, g2] rows (RCCL over xGMI when the process group is "nccl"; gloo in the CPU tests).
+Rows are summed in expert order k = 0..K-1 on every rank, so the result is bit-identical to the
+single-process loop of distributed_gp/BCM.cpp:153-198 whatever the number of ranks.
+
+The per-expert evaluator is injectable (`expert_factory`) so the sharding / reduction logic can be
+exercised on CPU ranks in the tests; the default builds `cugp_amd.gp.Covsum` handles on the GPU.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import gp as _gp
+
+
+def expert_owner(k, world):
+    """Reference placement: chunk k is handled by worker k mod W (cg_solver.cpp:93)."""
+    return k % world
+
+
+def split_rows(N, K):
+    """BCM::BCM row partition (BCM.cpp:85-110): floor(N/K) rows each, remainder to the last."""
+    part = N // K
+    return [(k * part, part if k < K - 1 else N - part * (K - 1)) for k in range(K)]
+
+
+def _default_factory(n, d, device):
+    return _gp.Covsum(n, d, device)
+
+
+class ShardedBCM:
+    """K experts over `world` ranks.  `experts` is a list of K (X_k, y_k) pairs; only the ones this
+    rank owns are touched (the rest may be None).  group=None with world==1 needs no process group."""
+
+    def __init__(self, experts, rank=0, world=1, device=0, group=None, expert_factory=None, comm_device=None):
+        self.K = len(experts)
+        self.rank, self.world, self.group = rank, world, group
+        self.mine = [k for k in range(self.K) if expert_owner(k, world) == rank]
+        factory = expert_factory or _default_factory
+        self.local = {}
+        for k in self.mine:
+            X, y = experts[k]
+            X = np.ascontiguousarray(X, dtype=np.float64)
+            y = np.ascontiguousarray(y, dtype=np.float64)
+            e = factory(X.shape[0], X.shape[1], device)
+            e.set_data(X, y)
+            self.local[k] = e
+        self.hp = np.zeros(3)
+        if comm_device is None:
+            comm_device = torch.device("cuda", device) if (world > 1 and dist.get_backend(group) == "nccl") \
+                else torch.device("cpu")
+        self.comm_device = comm_device
+        self._rows = torch.zeros((self.K, 4), dtype=torch.float64, device=comm_device)
+
+    # BCM::set_BCM_log_hyperparam (BCM.cpp:123-130): every expert gets the same vector
+    def set_loghyper(self, hp):
+        self.hp = np.array(hp, dtype=np.float64)
+        for e in self.local.values():
+            e.set_loghyperparam(self.hp)
+
+    def _allreduce(self, t):
+        if self.world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def loglik_grad(self):
+        """-> (sum_k LL_k, sum_k grad_k, per-expert LL[K]); one collective of K x 4 doubles."""
+        for k in self.mine:                       # all local experts in flight before the first fetch
+            self.local[k].enqueue(True)
+        rows = np.zeros((self.K, 4))
+        for k in self.mine:
+            ll, g = self.local[k].fetch()
+            rows[k, 0] = ll
+            rows[k, 1:] = g
+        self._rows.copy_(torch.from_numpy(rows))
+        out = self._allreduce(self._rows).cpu().numpy()
+        ll, g = 0.0, np.zeros(3)
+        for k in range(self.K):                   # expert order, as BCM.cpp:161-197
+            ll = ll + out[k, 0]
+            g = out[k, 1:].copy() if k == 0 else g + out[k, 1:]
+        return float(ll), g, out[:, 0].copy()
+
+    def predict(self, Xt):
+        """Product of experts (BCM.cpp:45-83): all-reduce of per-expert precision and precision*mean."""
+        Xt = np.ascontiguousarray(Xt, dtype=np.float64)
+        nt = Xt.shape[0]
+        buf = np.zeros((self.K, 2, nt))
+        for k in self.mine:
+            m, v = self.local[k].compute_test_means_and_variances(None, None, Xt)
+            buf[k, 0] = 1.0 / v
+            buf[k, 1] = (1.0 / v) * m
+        t = torch.from_numpy(buf).to(self.comm_device)
+        out = self._allreduce(t).cpu().numpy()
+        sp, spm = np.zeros(nt), np.zeros(nt)
+        for k in range(self.K):
+            sp += out[k, 0]
+            spm += out[k, 1]
+        return _gp.poe_finish(sp, spm)
+
+    def objective(self, theta):
+        self.set_loghyper(theta)
+        ll, g, _ = self.loglik_grad()
+        return -1.0 * ll, g
+
+    def cg_solve(self, budget=100):
+        """cg_solve(BCM) (distributed_ver1.cpp:13-232) -- the library's host loop on the all-reduced
+        objective; every rank runs it on identical numbers, so no hyper-parameter broadcast."""
+        theta, trace = _gp.cg_minimize(self.objective, self.hp, budget)
+        self.set_loghyper(theta)
+        return trace
+
+    def close(self):
+        for e in self.local.values():
+            if hasattr(e, "close"):
+                e.close()
+        self.local = {}

@@ -47,6 +47,7 @@ SIGNATURES = {
     "cugp_predict": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _dp]),
     "cugp_nlpp": (C.c_int, [_dp, _dp, _dp, C.c_int, _dp]),
     "cugp_compute_K_train": (C.c_int, [C.c_void_p, _dp]),
+    "cugp_compute_squared_dist": (C.c_int, [C.c_void_p, C.c_double, _dp]),
     "cugp_compute_k_test": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp]),
     "cugp_get_cholesky": (C.c_int, [C.c_void_p, _dp]),
     "cugp_get_K_inverse": (C.c_int, [C.c_void_p, _dp]),

@@ -504,6 +504,23 @@ int cugp_compute_K_train(cugp_gp* g, double* K)
     return CUGP_OK;
 }
 
+int cugp_compute_squared_dist(cugp_gp* g, double c, double* S)
+{
+    if (!g || !S) return CUGP_ERR_INVALID;
+    if (!g->have_data) return fail(CUGP_ERR_INVALID, "no training data set");
+    int rc;
+    if ((rc = use_device(g))) return rc;
+    if ((rc = fetch_eval(g))) return rc;
+    if ((rc = ensure(&g->dA, (size_t)g->npad * g->npad))) return rc;
+    g->factor_valid = g->inverse_valid = false;
+    launch_sqdist(g->dX, g->n, g->d, g->npad, c, g->dA, g->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy2DAsync(S, (size_t)g->n * sizeof(double), g->dA, (size_t)g->npad * sizeof(double),
+                            (size_t)g->n * sizeof(double), g->n, hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipStreamSynchronize(g->stream));
+    return CUGP_OK;
+}
+
 int cugp_compute_k_test(cugp_gp* g, const double* Xt, int nt, double* Ks)
 {
     if (!g || !Xt || !Ks || nt <= 0) return CUGP_ERR_INVALID;

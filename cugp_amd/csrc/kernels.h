@@ -15,6 +15,8 @@ struct HyperScalars {              // exp(2*theta) evaluated on the host, as the
 // lower 64x64 tiles of K (+ mirror when `full`), padding rows/cols >= n set to identity
 void launch_kbuild(const double* X, int n, int d, int npad, HyperScalars h, double* K, bool full,
                    hipStream_t s);
+// S[i][j] = |x_i - x_j|^2 / c, zero diagonal, full symmetric (N2, covkernel.cpp:130-157)
+void launch_sqdist(const double* X, int n, int d, int npad, double c, double* S, hipStream_t s);
 // Ks[t][i] = sf2 * exp(-0.5*|x_i - xt_t|^2 / l^2), row-major nt_pad x npad (pad = 0)   (N12)
 void launch_kcross(const double* X, int n, int d, int npad, const double* Xt, int nt, int ntpad,
                    HyperScalars h, double* Ks, hipStream_t s);

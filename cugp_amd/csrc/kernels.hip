@@ -368,7 +368,9 @@ __global__ __launch_bounds__(256) void k_build(const double* __restrict__ X, int
         for (int b = 0; b < 4; b++) {
             const int i = i0 + ty * 4 + a, j = j0 + tx * 4 + b;
             double v;
-            if (i < n && j < n) {
+            if (i < n && j < n && full == 2) {
+                v = (i == j) ? 0.0 : d2v[a][b] / h.ell_sq;               // covkernel.cpp:143-151 (squared distance / c)
+            } else if (i < n && j < n) {
                 v = h.signal_var * exp(-d2v[a][b] * 0.5 / h.ell_sq);     // covkernel.cpp:89
                 if (i == j) v += h.noise_var;                            // covkernel.cpp:93-94
             } else {
@@ -913,6 +915,12 @@ static inline int tri_count(int n) { return n * (n + 1) / 2; }
 void launch_kbuild(const double* X, int n, int d, int npad, HyperScalars h, double* K, bool full, hipStream_t s)
 {
     hipLaunchKernelGGL(k_build, dim3(tri_count(npad / KT)), dim3(256), 0, s, X, n, d, npad, h, K, full ? 1 : 0);
+}
+
+void launch_sqdist(const double* X, int n, int d, int npad, double c, double* S, hipStream_t s)
+{
+    HyperScalars h{c, 0.0, 0.0};
+    hipLaunchKernelGGL(k_build, dim3(tri_count(npad / KT)), dim3(256), 0, s, X, n, d, npad, h, S, 2);
 }
 
 void launch_kcross(const double* X, int n, int d, int npad, const double* Xt, int nt, int ntpad, HyperScalars h,

@@ -116,6 +116,11 @@ class Covsum:
         check(capi.lib().cugp_compute_K_train(self._h, ptr(K)))
         return K
 
+    def compute_squared_dist(self, c):
+        S = np.empty((self.n, self.n))
+        check(capi.lib().cugp_compute_squared_dist(self._h, float(c), ptr(S)))
+        return S
+
     def compute_k_test(self, Xt):
         Xt = f64(Xt).reshape(-1, self.d)
         Ks = np.empty((Xt.shape[0], self.n))

@@ -79,11 +79,13 @@ int cugp_nlpp(const double *actual, const double *mean, const double *var, int n
 
 /* ---- intermediates (parity tests; each copies device -> host) ----
  * cugp_compute_K_train : Covsum::compute_K_train covkernel.cpp:64-102 -> full symmetric n x n
+ * cugp_compute_squared_dist : Covsum::compute_squared_dist covkernel.cpp:130-157 -> |xi-xj|^2 / c, zero diagonal
  * cugp_compute_k_test  : Covsum::compute_k_test covkernel.cpp:105-116 -> nt x n
  * cugp_get_cholesky    : get_cholesky matrixops.cpp:68-108 -> lower factor of the last evaluation, upper zeroed
  * cugp_get_K_inverse   : compute_K_inverse matrixops.cpp:383-435 -> full symmetric (needs a gradient evaluation)
  * cugp_get_alpha       : vector_Kinvy_using_cholesky matrixops.cpp:264-316 (needs a gradient evaluation) */
 int cugp_compute_K_train(cugp_gp *gp, double *K);
+int cugp_compute_squared_dist(cugp_gp *gp, double c, double *S);
 int cugp_compute_k_test(cugp_gp *gp, const double *Xt, int nt, double *Ks);
 int cugp_get_cholesky(cugp_gp *gp, double *L);
 int cugp_get_K_inverse(cugp_gp *gp, double *Kinv);

@@ -1,0 +1,62 @@
+"""The C++ drop-in layer (cugp_amd/host: class Covsum, class BCM, free-function surface) compiled into a
+driver that calls it the way the reference's own mains call theirs, checked against the oracle."""
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cpp_dropin_driver(tmp_path, si128, golden_si128, oracle):
+    X, y = si128
+    ntrain = 120
+    Xall = np.vstack([X[:ntrain], np.array(golden_si128["bcm"]["Xt"])])
+    yall = np.concatenate([y[:ntrain], y[:3], y[:5]])
+    inp, lab = tmp_path / "in.txt", tmp_path / "lab.txt"
+    with open(inp, "w") as f:
+        f.write("%d %d\n" % Xall.shape)
+        for r in Xall:
+            f.write(" ".join(repr(float(v)) for v in r) + "\n")
+    with open(lab, "w") as f:
+        f.write("\n".join(repr(float(v)) for v in yall) + "\n")
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "cugp_amd", "host")])
+    exe = str(tmp_path / "dropin_driver")
+    libdir = os.path.join(ROOT, "cugp_amd", "lib")
+    subprocess.check_call(["g++", "-O1", "-std=c++14", os.path.join(ROOT, "tests", "cpp", "dropin_driver.cpp"),
+                           "-o", exe, "-L" + libdir, "-lcugp_host", "-lcugp", "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe, str(inp), str(lab), str(ntrain), "4"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-2000:])
+    txt = out.stdout
+    js = txt[txt.index("{"):]
+    js = re.sub(r"\n+ PLEASE-SEE 3[^\n]*\n+", "\n", js)
+    r = json.loads(js)
+
+    o = oracle
+    Xtr, ytr, Xt = Xall[:ntrain], yall[:ntrain], Xall[ntrain:]
+    hp = [1.5, 1.5, 1.5]
+    llo, gro = o.loglik_grad(Xtr, ytr, hp)
+    assert abs(r["ll"] - llo) <= 1e-8 * abs(llo) and np.allclose(r["grad"], gro, rtol=1e-7, atol=1e-7)
+    assert abs(r["api_ll"] - llo) <= 1e-8 * abs(llo) and np.allclose(r["api_grad"], gro, rtol=1e-7, atol=1e-7)
+    mo, vo = o.predict(Xtr, ytr, hp, Xt)
+    assert np.allclose(r["pred_mean"], mo, rtol=1e-8, atol=1e-8) and np.allclose(r["pred_var"], vo, rtol=1e-8, atol=1e-8)
+    assert abs(r["nlpp"] - o.nlpp(yall[ntrain:], mo, vo)) <= 1e-8
+    fin, _ = o.cg_solve(Xtr, ytr, hp)
+    assert np.allclose(r["cg_final_hp"], fin, atol=5e-5) and np.allclose(r["api_cg_final_hp"], fin, atol=5e-5)
+    assert abs(r["cg_final_ll"] - o.loglik(Xtr, ytr, fin)) <= 1e-5
+    Ko = o.K_train(Xtr, r["cg_final_hp"])
+    assert np.allclose(r["K_row5"], Ko[5], rtol=1e-12, atol=1e-14)
+    assert r["param_dim"] == 2
+    b = o.bcm(Xtr, ytr, 4, hp)
+    assert abs(r["bcm_ll"] - b.loglik()[0]) <= 1e-8 * abs(r["bcm_ll"])
+    assert np.allclose(r["bcm_grad"], b.grad(), rtol=1e-7, atol=1e-7)
+    bm, bv = b.predict(Xt)
+    assert np.allclose(r["bcm_pred_mean"], bm, rtol=1e-8, atol=1e-8)
+    assert np.allclose(r["bcm_pred_var"], bv, rtol=1e-8, atol=1e-8)
+    bf, _ = b.cg_solve()
+    assert np.allclose(r["bcm_cg_final_hp"], bf, atol=5e-5)

@@ -1,0 +1,131 @@
+"""Host logic of the product library that needs no GPU: the optimisers (minimize.cpp) against the
+oracle's restatement on identical callbacks, the scalar prediction helpers, the row partition and the
+ctypes surface.  The library is LOADED here (hipcc cross-compiled it) but no device call is made."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import cugp_amd.gp as gp
+from cugp_amd import capi
+from cugp_amd.bcm import expert_owner, split_rows
+from conftest import HP_BCM, ROOT
+
+
+def test_header_symbols_all_exported_and_bound():
+    text = open(os.path.join(ROOT, "include", "cugp.h")).read()
+    declared = set(re.findall(r"\b(cugp_[A-Za-z0-9_]+)\s*\(", text))
+    declared -= {"cugp_objective_fn"}
+    lib = capi.lib()
+    missing = [n for n in sorted(declared) if not hasattr(lib, n)]
+    assert not missing, missing
+    assert declared == set(capi.SIGNATURES), declared ^ set(capi.SIGNATURES)
+    assert lib.cugp_version() >= 100
+
+
+def test_no_device_is_an_error_not_a_fallback():
+    """Without a GPU the product path must fail loudly (error code + message), never compute on the CPU."""
+    lib = capi.lib()
+    n = C.c_int(-1)
+    rc = lib.cugp_device_count(C.byref(n))
+    if rc == 0 and n.value > 0:
+        pytest.skip("a GPU is visible")
+    h = C.c_void_p()
+    rc = lib.cugp_create(16, 2, 0, C.byref(h))
+    assert rc == -4 and not h.value
+    assert b"no HIP device" in lib.cugp_last_error()
+    with pytest.raises(capi.CugpError):
+        gp.Covsum(16, 2)
+    with pytest.raises(capi.CugpError):
+        gp.potrf(np.eye(4))
+
+
+def test_argument_validation():
+    lib = capi.lib()
+    assert lib.cugp_create(0, 2, 0, C.byref(C.c_void_p())) == -1
+    assert lib.cugp_cg_minimize(capi.OBJECTIVE(lambda *a: None), None, None, 10, None, 0, None) == -1
+    assert lib.cugp_destroy(None) == 0 and lib.cugp_bcm_destroy(None) == 0
+    out = C.c_double()
+    assert lib.cugp_nlpp(None, None, None, 3, C.byref(out)) == -1
+
+
+def _oracle_objective(oracle, X, y):
+    def fn(th):
+        return -oracle.loglik(X, y, th), oracle.grad(X, y, th)
+    return fn
+
+
+def test_cg_minimize_bitwise_vs_oracle(oracle, si128):
+    """Same callback, same start: the library's CG loop and the oracle's must take identical steps."""
+    X, y = si128
+    fn = _oracle_objective(oracle, X[:48], y[:48])
+    th_lib, tr_lib = gp.cg_minimize(fn, HP_BCM, 60)
+    th_or, tr_or = oracle.cg_minimize(fn, HP_BCM, 60)
+    assert tr_lib.shape == tr_or.shape
+    assert np.array_equal(tr_lib, tr_or)
+    assert np.array_equal(th_lib, th_or)
+
+
+def test_cg_minimize_reproduces_reference_run(oracle, si128, golden_si128):
+    X, y = si128
+    c = golden_si128["cg"][0]
+    th, tr = gp.cg_minimize(_oracle_objective(oracle, X, y), c["hp0"], 100)
+    assert np.allclose(th, c["final_hp"], rtol=0, atol=1e-12)
+    probes = np.array([p[1:] for p in c["please_see"] if p[0] in (1, 2)])
+    assert np.allclose(tr[1:, :3], probes, atol=6e-7)
+
+
+def test_cg_minimize_nan_bisects(oracle):
+    """A probe that returns NaN (non-PD covariance) halves the step instead of aborting
+    (covkernel.cpp:509-524): the probe after the NaN one is the midpoint (x2 + x3) / 2 with x2 = 0."""
+    def make():
+        count = [0]
+
+        def fn(th):
+            count[0] += 1
+            if count[0] == 2:
+                return float("nan"), np.array([np.nan, 0.0, 0.0])
+            f = (th[0] - 0.5) ** 2 + 2 * (th[1] + 1) ** 2 + 0.5 * th[2] ** 2
+            return f, np.array([2 * (th[0] - 0.5), 4 * (th[1] + 1), th[2]])
+        return fn
+    start = np.array([-3.0, 2.0, 1.0])
+    th, tr = gp.cg_minimize(make(), start, 40)
+    assert np.isnan(tr[1, 3]) and np.isfinite(tr[2, 3])
+    assert np.allclose(tr[2, :3] - start, 0.5 * (tr[1, :3] - start), rtol=1e-12, atol=1e-15)
+    assert np.isfinite(tr[-1, 3]) and np.allclose(th, [0.5, -1.0, 0.0], atol=1e-4)
+    th2, tr2 = oracle.cg_minimize(make(), start, 40)
+    assert np.array_equal(tr[~np.isnan(tr[:, 3])], tr2[~np.isnan(tr2[:, 3])]) and np.array_equal(th, th2)
+
+
+def test_rprop_minimize_bitwise_vs_oracle(oracle, si128):
+    X, y = si128
+    fn = _oracle_objective(oracle, X[:40], y[:40])
+    th_lib, tr_lib = gp.rprop_minimize(fn, HP_BCM, 25)
+    th_or, tr_or = oracle.rprop_minimize(fn, HP_BCM, 25)
+    assert np.array_equal(tr_lib, tr_or) and np.array_equal(th_lib, th_or)
+
+
+def test_nlpp_and_poe_vs_oracle(oracle):
+    rng = np.random.default_rng(1)
+    a, m, v = rng.standard_normal(9), rng.standard_normal(9), rng.uniform(0.1, 3, 9)
+    assert gp.Covsum.get_negative_log_predprob(a, m, v) == oracle.nlpp(a, m, v)
+    means, vars_ = rng.standard_normal((5, 9)), rng.uniform(0.1, 3, (5, 9))
+    sp = np.zeros(9)
+    spm = np.zeros(9)
+    for e in range(5):                      # BCM.cpp:51-55 accumulation order
+        inv = 1.0 / vars_[e]
+        sp += inv
+        spm += inv * means[e]
+    pm, pv = gp.poe_finish(sp, spm)
+    om, ov = oracle.poe(means, vars_)
+    assert np.array_equal(pm, om) and np.array_equal(pv, ov)
+
+
+def test_row_partition_matches_reference(oracle, si128):
+    X, y = si128
+    for K in (1, 3, 4, 7):
+        b = oracle.bcm(X, y, K, HP_BCM)
+        assert split_rows(128, K) == [b.expert_rows(k) for k in range(K)]
+    assert [expert_owner(k, 3) for k in range(7)] == [0, 1, 2, 0, 1, 2, 0]     # chunk i -> worker i mod W
