@@ -56,6 +56,7 @@ struct cugp_gp {
     double *dX = nullptr, *dy = nullptr, *dA = nullptr, *dT = nullptr, *dU = nullptr, *dKinv = nullptr;
     double *dz = nullptr, *dalpha = nullptr, *dw = nullptr, *d16 = nullptr, *dlogdet = nullptr, *dpart = nullptr;
     double* dout = nullptr;
+    unsigned* dtickets = nullptr;  // one arrival counter per factorisation step (k_syrk_step)
     double* hout = nullptr;        // pinned, 8 doubles
     int nblocks_trace = 0;
     double hp[3] = {0, 0, 0};
@@ -126,39 +127,27 @@ void drain_kernel_events(cugp_gp* g)
     g->kev_used = 0;
 }
 
-// Blocked right-looking Cholesky of A (lower) with depth-1 look-ahead on two HIP streams:
-//   chain (high priority): [update of the NEXT diagonal tile] -> potf2 of it           -> P[k+1]
-//   main                 : wait P[k] -> panel solve(k) -> R[k] -> trailing update(k) without that tile
-// so the latency-bound diagonal block of step k+1 runs beside the MFMA-bound trailing update of step k.
+// Blocked right-looking Cholesky of A (lower), one stream, two launches per step:
+//   panel solve(k)  ->  [trailing update(k) + factorisation of diagonal block k+1] in ONE launch
+// (k_syrk_step: the latency-bound diagonal block runs inside the MFMA-bound trailing update).
 int enqueue_potrf(cugp_gp* g)
 {
-    hipStream_t m = g->stream, c = g->chain;
+    hipStream_t m = g->stream;
     const int nt = g->nt, ld = g->npad;
-    HIPCHK(hipEventRecord(g->ev_r[nt], m));                 // everything before (kernel build / upload)
-    HIPCHK(hipStreamWaitEvent(c, g->ev_r[nt], 0));
-    launch_potf2(g->dA, ld, 0, g->d16, g->dlogdet, c);
-    HIPCHK(hipEventRecord(g->ev_p[0], c));
+    HIPCHK(hipMemsetAsync(g->dtickets, 0, (size_t)nt * sizeof(unsigned), m));
+    launch_potf2(g->dA, ld, 0, g->d16, g->dlogdet, m);
     for (int kb = 0; kb + 1 < nt; kb++) {
-        HIPCHK(hipStreamWaitEvent(m, g->ev_p[kb], 0));
         launch_trsm_strips(g->dA, g->d16, ld, kb, nt, m);
-        HIPCHK(hipEventRecord(g->ev_r[kb], m));
-        HIPCHK(hipStreamWaitEvent(c, g->ev_r[kb], 0));
-        launch_syrk_diag(g->dA, ld, kb, c);
-        launch_potf2(g->dA, ld, kb + 1, g->d16, g->dlogdet, c);
-        HIPCHK(hipEventRecord(g->ev_p[kb + 1], c));
-        if (nt - kb - 1 > 1) {
-            const bool ev = g->prof >= 2 && g->kev_used + 2 <= (int)g->kev.size();
-            if (ev) HIPCHK(hipEventRecord(g->kev[g->kev_used], m));
-            launch_syrk_trail(g->dA, ld, kb, nt, true, m);
-            if (ev) {
-                HIPCHK(hipEventRecord(g->kev[g->kev_used + 1], m));
-                g->kev_used += 2;
-                const double me = (double)(nt - kb - 1) * TILE;
-                g->kev_flop += (me * me - (double)TILE * TILE) * TILE;   // lower triangle, mul+add, minus the diag tile
-            }
+        const bool ev = g->prof >= 2 && g->kev_used + 2 <= (int)g->kev.size();
+        if (ev) HIPCHK(hipEventRecord(g->kev[g->kev_used], m));
+        launch_syrk_step(g->dA, ld, kb, nt, g->d16, g->dlogdet, g->dtickets, m);
+        if (ev) {
+            HIPCHK(hipEventRecord(g->kev[g->kev_used + 1], m));
+            g->kev_used += 2;
+            const double me = (double)(nt - kb - 1) * TILE;
+            g->kev_flop += me * me * TILE;                  // lower triangle only: m^2 * nb (mul+add)
         }
     }
-    HIPCHK(hipStreamWaitEvent(m, g->ev_p[nt - 1], 0));
     // inverses of all diagonal factor blocks at once (off the factorisation's critical path)
     launch_trtri_diag(g->dA, ld, 0, nt, g->d16, g->dT, g->dU, m);
     HIPCHK(hipGetLastError());
@@ -296,6 +285,7 @@ int cugp_create(int n, int d, int device, cugp_gp** out)
     if (e == hipSuccess) e = hipMalloc((void**)&g->dlogdet, (size_t)g->nt * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&g->dpart, (size_t)g->nblocks_trace * 3 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&g->dout, 8 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&g->dtickets, (size_t)g->nt * sizeof(unsigned));
     if (e == hipSuccess) e = hipHostMalloc((void**)&g->hout, 8 * sizeof(double), hipHostMallocDefault);
     for (int i = 0; i <= NPHASE && e == hipSuccess; i++) e = hipEventCreate(&g->pev[i]);
     if (e != hipSuccess) {
@@ -317,6 +307,7 @@ int cugp_destroy(cugp_gp* g)
                       g->dpart, g->dout};
     for (double* p : bufs)
         if (p) (void)hipFree(p);
+    if (g->dtickets) (void)hipFree(g->dtickets);
     if (g->hout) (void)hipHostFree(g->hout);
     for (int i = 0; i <= NPHASE; i++)
         if (g->pev[i]) (void)hipEventDestroy(g->pev[i]);

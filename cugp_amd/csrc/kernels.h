@@ -28,7 +28,10 @@ void launch_trtri_diag(const double* A, int ld, int kb, int nblocks, const doubl
 void launch_trsm_panel(double* A, const double* T, int ld, int kb, int nt, hipStream_t s);   // L21 = A21 T11^T (GEMM form)
 void launch_trsm_strips(double* A, const double* d16, int ld, int kb, int nt, hipStream_t s);   // block substitution
 void launch_syrk_trail(double* A, int ld, int kb, int nt, bool skip_next_diag, hipStream_t s);
-void launch_syrk_diag(double* A, int ld, int kb, hipStream_t s);    // tile (kb+1,kb+1) only, fine grained
+void launch_syrk_diag(double* A, int ld, int kb, hipStream_t s);
+// trailing update of step kb fused with the factorisation of diagonal block kb+1 (tickets[kb] must be 0)
+void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* logdet_part, unsigned* tickets,
+                      hipStream_t s);    // tile (kb+1,kb+1) only, fine grained
 
 // ---- triangular inverse by recursive doubling (N7) and K^-1 = U U^T (N8) ----
 void launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, int s, int step, hipStream_t st);

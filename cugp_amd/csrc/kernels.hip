@@ -173,18 +173,42 @@ __device__ __forceinline__ void tile_store(double* __restrict__ C, int ldc, cons
                     (d2){alpha * acc[m][2 * np][r], alpha * acc[m][2 * np + 1][r]};
 }
 
-// Ct[col][row] = alpha*acc  (transposed store)
-__device__ __forceinline__ void tile_store_t(double* __restrict__ Ct, int ldc, const d4 (&acc)[4][4], double alpha)
+// Ct[col][row] = alpha*acc  (transposed store).  The tile is turned through LDS (free after the K loop)
+// in two 64-row halves so that global stores are whole 512-byte runs; the LDS image [col][64 rows] is
+// XOR-swizzled on the row index so the accumulator-layout writes do not pile onto one bank.
+// All 256 threads must call.
+__device__ __forceinline__ void tile_store_t(double* __restrict__ Ct, int ldc, const d4 (&acc)[4][4], double alpha,
+                                             char* smem)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wr = wave >> 1, wc = wave & 1;
+    double* sd = (double*)smem;
 #pragma unroll
-    for (int m = 0; m < 4; m++)
+    for (int h = 0; h < 2; h++) {
+        __syncthreads();
+        if (wr == h) {
 #pragma unroll
-        for (int n = 0; n < 4; n++)
+            for (int m = 0; m < 4; m++)
 #pragma unroll
-            for (int r = 0; r < 4; r++)
-                Ct[(size_t)(ACC_COL2(n >> 1) + (n & 1)) * ldc + ACC_ROW(m, r)] = alpha * acc[m][n][r];
+                for (int n = 0; n < 4; n++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int col = ACC_COL2(n >> 1) + (n & 1);
+                        const int rr = m * 16 + (lane >> 4) + 4 * r;
+                        sd[col * 64 + (rr ^ ((col >> 1) & 15))] = alpha * acc[m][n][r];
+                    }
+        }
+        __syncthreads();
+        // 8 column-rows per pass: 32 lanes x 2 doubles = one 64-row run
+        const int rr = (t & 31) * 2;
+#pragma unroll
+        for (int pass = 0; pass < 16; pass++) {
+            const int col = pass * 8 + (t >> 5);
+            const int sw = (col >> 1) & 15;
+            const d2 v = (d2){sd[col * 64 + (rr ^ sw)], sd[col * 64 + ((rr + 1) ^ sw)]};
+            *(d2*)(Ct + (size_t)col * ldc + h * 64 + rr) = v;
+        }
+    }
 }
 
 // lower-triangular tile index: idx -> (ti >= tj)
@@ -253,7 +277,10 @@ __global__ __launch_bounds__(256, 2) void k_trtri_level(const double* __restrict
     const int b0 = a0 + s;
     int sb = nt - b0;
     if (sb > s) sb = s;
-    const int ja = rem / sb, ib = rem % sb;              // tile in A (column block), tile in B (row block)
+    // tile in A (column block), tile in B (row block); longest k range first in both steps
+    // (step 1: k from tj to the end of A -> ja ascending; step 2: k from b0 to ti -> ib descending)
+    const int ja = (step == 1) ? rem / sb : rem % s;
+    const int ib = (step == 1) ? rem % sb : sb - 1 - rem / s;
     const int tj = a0 + ja, ti = b0 + ib;
     d4 acc[4][4];
     acc_zero(acc);
@@ -265,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void k_trtri_level(const double* __restrict
         tile_nt<true>(T + (size_t)ti * TILE * ld, ld, T + (size_t)tj * TILE * ld, ld, b0 * TILE, (ti + 1) * TILE,
                       acc, smem);
         tile_store(T + (size_t)ti * TILE * ld + tj * TILE, ld, acc, 1.0);
-        tile_store_t(U + (size_t)tj * TILE * ld + ti * TILE, ld, acc, 1.0);
+        tile_store_t(U + (size_t)tj * TILE * ld + ti * TILE, ld, acc, 1.0, smem);
     }
 }
 
@@ -460,6 +487,9 @@ __device__ __forceinline__ double rsqrt_nr(double x)
 
 // Cholesky of one 16x16 micro tile held in LDS (rows padded to 17), by ONE wave: lane l owns row
 // l & 15 in registers, right-looking, pivots and column factors broadcast with v_readlane.
+// The pivot chain is the latency floor of the whole factorisation, so it is kept short: the second
+// Newton step of 1/sqrt(pivot) is folded into the column scaling, and the next pivot is formed
+// first (each lane with its own factor: lane c+1 holds the right value) before the general update.
 // Writes the factor back (upper zeroed) and 1/L_cc into rinv[0..15].
 __device__ __forceinline__ void micro_factor(double* __restrict__ tile, double* __restrict__ rinv)
 {
@@ -467,13 +497,22 @@ __device__ __forceinline__ void micro_factor(double* __restrict__ tile, double* 
     double r[MT];
 #pragma unroll
     for (int c = 0; c < MT; c++) r[c] = tile[i * (MT + 1) + c];
+    double piv = readlane_f64(r[0], 0);
 #pragma unroll
     for (int c = 0; c < MT; c++) {
-        const double piv = readlane_f64(r[c], c);
-        const double rs = rsqrt_nr(piv);
-        const double lc = r[c] * rs;
+        // y1 = rsq + one Newton step (2^-48); second step folded: l = a*y1 + (a*h1)*e1  (2^-52.7 measured)
+        double y = __builtin_amdgcn_rsq(piv);
+        const double e0 = __builtin_fma(-piv * y, y, 1.0);
+        y = __builtin_fma(0.5 * y, e0, y);
+        const double e1 = __builtin_fma(-piv * y, y, 1.0);
+        const double h1 = 0.5 * y;
+        const double lc = __builtin_fma(r[c] * h1, e1, r[c] * y);
         r[c] = lc;
-        if (lane == c) rinv[c] = rs;
+        if (c + 1 < MT) {
+            const double dn = __builtin_fma(-lc, lc, r[c + 1]);      // lane c+1: next pivot
+            piv = readlane_f64(dn, c + 1);
+        }
+        if (lane == c) rinv[c] = __builtin_fma(h1, e1, y);
 #pragma unroll
         for (int c2 = c + 1; c2 < MT; c2++) {
             const double o = readlane_f64(lc, c2);
@@ -483,6 +522,25 @@ __device__ __forceinline__ void micro_factor(double* __restrict__ tile, double* 
     if (lane < MT) {
 #pragma unroll
         for (int c = 0; c < MT; c++) tile[i * (MT + 1) + c] = (c <= i) ? r[c] : 0.0;
+    }
+}
+
+// inverse of one factored 16x16 micro tile: lane j builds column j of L^-1 by forward substitution
+__device__ __forceinline__ void micro_inverse(const double* __restrict__ Ljj, const double* __restrict__ rinv,
+                                              double* __restrict__ dst)
+{
+    const int lane = threadIdx.x & 63, j = lane & 15;
+    double tc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; i++) {
+        double sacc = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; k++) sacc = __builtin_fma(-Ljj[i * (MT + 1) + k], tc[k], sacc);
+        tc[i] = sacc * rinv[i];
+    }
+    if (lane < MT) {
+#pragma unroll
+        for (int i = 0; i < MT; i++) dst[i * MT + j] = tc[i];
     }
 }
 
@@ -516,15 +574,29 @@ __device__ __forceinline__ void micro_update(double* __restrict__ sm, int bi, in
 // Outputs: L (lower) back into A, the 16x16 diagonal inverses (d16, used by the panel solve and
 // the inverse), and this block's share of log|K|.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_potf2(double* __restrict__ A, int ld, int kb, double* __restrict__ d16,
-                                               double* __restrict__ logdet_part)
-{
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    double* rinv = sm + NLT * MTS;                          // 1 / L_ii, 128 entries
-    __shared__ double red[TILE];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    double* Ab = A + (size_t)kb * TILE * ld + kb * TILE;
+#ifdef CUGP_STAMPS   // diagnostic build only (tools/chain_bench.hip): cycle stamps of wave 0 into a side buffer
+__device__ unsigned long long g_stamps[64];
+#define STAMP(i)                                                                   \
+    do {                                                                           \
+        if (threadIdx.x == 0) {                                                    \
+            unsigned long long t_;                                                 \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+            g_stamps[i] = t_;                                                      \
+        }                                                                          \
+    } while (0)
+#else
+#define STAMP(i)
+#endif
 
+__device__ __forceinline__ void potf2_body(double* __restrict__ Ab, int ld, double* __restrict__ d16blk,
+                                           double* __restrict__ logdet_out, double* __restrict__ sm,
+                                           double* __restrict__ red)
+{
+    double* rinv = sm + NLT * MTS;                          // 1 / L_ii, 128 entries
+    const int t = threadIdx.x, wave = t >> 6;
+    __builtin_amdgcn_s_setprio(3);                          // this workgroup is the critical path of the step
+
+    STAMP(0);
     {   // load the lower micro tiles; thread t = element (t>>4, t&15) of every tile
         const int r = t >> 4, c = t & 15;
         for (int bi = 0; bi < NMT; bi++)
@@ -532,8 +604,10 @@ __global__ __launch_bounds__(256) void k_potf2(double* __restrict__ A, int ld, i
                 sm[mt_off(bi, bj) + r * (MT + 1) + c] = Ab[(size_t)(bi * MT + r) * ld + bj * MT + c];
     }
     __syncthreads();
+    STAMP(1);
     if (wave == 0) micro_factor(sm + mt_off(0, 0), rinv);
     __syncthreads();
+    STAMP(2);
 
     for (int jb = 0; jb < NMT - 1; jb++) {
         const int m = NMT - 1 - jb;                         // micro tiles below the diagonal one
@@ -554,11 +628,14 @@ __global__ __launch_bounds__(256) void k_potf2(double* __restrict__ A, int ld, i
             for (int c = 0; c < MT; c++) row[c] = x[c];
         }
         __syncthreads();
+        STAMP(3 + 3 * jb);
         // (C) trailing micro tiles of this 128 block
         if (wave == 0) {
             micro_update(sm, jb + 1, jb + 1, jb);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            STAMP(4 + 3 * jb);
             micro_factor(sm + mt_off(jb + 1, jb + 1), rinv + (jb + 1) * MT);
+            STAMP(5 + 3 * jb);
         } else {
             int n = 0;                                      // column jb+1 first, then the rest
             for (int bi = jb + 2; bi < NMT; bi++, n++)
@@ -566,34 +643,23 @@ __global__ __launch_bounds__(256) void k_potf2(double* __restrict__ A, int ld, i
             for (int bj = jb + 2; bj < NMT; bj++)
                 for (int bi = bj; bi < NMT; bi++, n++)
                     if (n % 3 == wave - 1) micro_update(sm, bi, bj, jb);
+            // the inverse of the diagonal micro tile just finished, by a wave that has slack
+            if (wave == 1 + (jb % 3))
+                micro_inverse(sm + mt_off(jb, jb), rinv + jb * MT, d16blk + (size_t)jb * (MT * MT));
         }
         __syncthreads();
     }
 
+    STAMP(30);
+    if (wave == 1)
+        micro_inverse(sm + mt_off(NMT - 1, NMT - 1), rinv + (NMT - 1) * MT, d16blk + (size_t)(NMT - 1) * (MT * MT));
     {   // factor back to global (lower micro tiles; diagonal tiles carry zeros above the diagonal)
         const int r = t >> 4, c = t & 15;
         for (int bi = 0; bi < NMT; bi++)
             for (int bj = 0; bj <= bi; bj++)
                 Ab[(size_t)(bi * MT + r) * ld + bj * MT + c] = sm[mt_off(bi, bj) + r * (MT + 1) + c];
     }
-    // inverses of the 16x16 diagonal factors: lane j builds column j by forward substitution
-    for (int jb = wave; jb < NMT; jb += 4) {
-        const int j = lane & 15;
-        const double* Ljj = sm + mt_off(jb, jb);
-        double tc[MT];
-#pragma unroll
-        for (int i = 0; i < MT; i++) {
-            double sacc = (i == j) ? 1.0 : 0.0;
-#pragma unroll
-            for (int k = 0; k < i; k++) sacc = __builtin_fma(-Ljj[i * (MT + 1) + k], tc[k], sacc);
-            tc[i] = sacc * rinv[jb * MT + i];
-        }
-        if (lane < MT) {
-            double* dst = d16 + ((size_t)kb * NMT + jb) * (MT * MT);
-#pragma unroll
-            for (int i = 0; i < MT; i++) dst[i * MT + j] = tc[i];
-        }
-    }
+    STAMP(31);
     // log-determinant share of this block, summed in a fixed order: log L_ii = -log(1/L_ii)
     if (t < TILE) red[t] = -log(rinv[t]);
     __syncthreads();
@@ -601,17 +667,25 @@ __global__ __launch_bounds__(256) void k_potf2(double* __restrict__ A, int ld, i
         if (t < w) red[t] += red[t + w];
         __syncthreads();
     }
-    if (t == 0) logdet_part[kb] = red[0];
+    if (t == 0) *logdet_out = red[0];
+    STAMP(32);
 }
 
-// next diagonal tile only: A(kb+1,kb+1) -= L(kb+1,kb) L(kb+1,kb)^T, one WAVE per 16x16 micro tile (36 waves),
-// operands straight from L2 -- the short kernel that lets the next diagonal block start while the big
-// trailing update is still running on the other stream
-__global__ __launch_bounds__(256) void k_syrk_diag(double* __restrict__ A, int ld, int kb)
+__global__ __launch_bounds__(256) void k_potf2(double* __restrict__ A, int ld, int kb, double* __restrict__ d16,
+                                               double* __restrict__ logdet_part)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ double red[TILE];
+    potf2_body(A + (size_t)kb * TILE * ld + kb * TILE, ld, d16 + (size_t)kb * NMT * (MT * MT), logdet_part + kb, sm,
+               red);
+}
+
+// one 16x16 micro tile of A(kb+1,kb+1) -= L(kb+1,kb) L(kb+1,kb)^T, by one wave, operands straight from L2
+__device__ __forceinline__ void diag_update_wave(double* __restrict__ A, int ld, int kb, int mtile)
+{
+    const int lane = threadIdx.x & 63;
     int bi, bj;
-    tri_index(blockIdx.x * 4 + wave, bi, bj);
+    tri_index(mtile, bi, bj);
     const int c = lane & 15, g = lane >> 4;
     const int k0 = kb * TILE, i0 = (kb + 1) * TILE;
     const double* Li = A + (size_t)(i0 + bi * MT + c) * ld + k0 + g;
@@ -620,11 +694,69 @@ __global__ __launch_bounds__(256) void k_syrk_diag(double* __restrict__ A, int l
     d4 acc;
 #pragma unroll
     for (int r = 0; r < 4; r++) acc[r] = C[(size_t)(4 * r) * ld];
-#pragma unroll 8
+    double la[TILE / 4], lb[TILE / 4];                 // all operands in flight before the first MFMA
+#pragma unroll
+    for (int s = 0; s < TILE / 4; s++) { la[s] = Li[4 * s]; lb[s] = Lj[4 * s]; }
+#pragma unroll
     for (int s = 0; s < TILE / 4; s++)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Li[4 * s], Lj[4 * s], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-la[s], lb[s], acc, 0, 0, 0);
 #pragma unroll
     for (int r = 0; r < 4; r++) C[(size_t)(4 * r) * ld] = acc[r];
+}
+
+__global__ __launch_bounds__(256) void k_syrk_diag(double* __restrict__ A, int ld, int kb)
+{
+    diag_update_wave(A, ld, kb, blockIdx.x * 4 + (threadIdx.x >> 6));
+}
+
+// ------------------------------------------------------------------------------------------
+// One launch per factorisation step kb: the trailing update A22 -= L21 L21^T AND, inside it, the
+// factorisation of the NEXT diagonal block.  Workgroups 0..8 (dispatched first) update the 36 micro
+// tiles of tile (kb+1,kb+1) straight from L2; the last of them to finish (agent-scope release ->
+// ticket -> acquire, no spinning) goes on to factor that block (potf2_body) while the other
+// workgroups of the launch run the MFMA tile products of the rest of the trailing matrix.  The
+// latency-bound diagonal block therefore never waits for a free CU slot and needs no second stream.
+// ------------------------------------------------------------------------------------------
+constexpr int NDIAGWG = NLT / 4;                      // 9 workgroups x 4 waves = 36 micro tiles
+constexpr int STEP_LDS = POTF2_LDS;                   // >= GEMM_LDS; two such workgroups still fit one CU
+
+__global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, int ld, int kb,
+                                                      double* __restrict__ d16, double* __restrict__ logdet_part,
+                                                      unsigned* __restrict__ tickets)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    __shared__ double red[TILE];
+    __shared__ unsigned s_ticket;
+    if (blockIdx.x < NDIAGWG) {
+        diag_update_wave(A, ld, kb, blockIdx.x * 4 + (threadIdx.x >> 6));
+        // publish (cdna guide G16, counter form): drain my stores, workgroup barrier, agent release, ticket
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            s_ticket = __hip_atomic_fetch_add(&tickets[kb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (s_ticket != NDIAGWG - 1) return;           // not the last arriver
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        const int kn = kb + 1;
+        potf2_body(A + (size_t)kn * TILE * ld + kn * TILE, ld, d16 + (size_t)kn * NMT * (MT * MT), logdet_part + kn,
+                   sm, red);
+        return;
+    }
+    int ti, tj;
+    tri_index(blockIdx.x - NDIAGWG + 1, ti, tj);      // tile 0 = (kb+1,kb+1) is the diagonal one above
+    const int k0 = kb * TILE;
+    const int i0 = (kb + 1 + ti) * TILE, j0 = (kb + 1 + tj) * TILE;
+    d4 acc[4][4];
+    tile_load(A + (size_t)i0 * ld + j0, ld, acc);
+    tile_nt<true>(A + (size_t)i0 * ld + k0, ld, A + (size_t)j0 * ld + k0, ld, 0, TILE, acc, (char*)sm);
+    tile_store(A + (size_t)i0 * ld + j0, ld, acc, 1.0);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -935,6 +1067,7 @@ static void set_big_lds()
 {
     if (g_attr_done) return;
     (void)hipFuncSetAttribute((const void*)k_potf2, hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_LDS);
+    (void)hipFuncSetAttribute((const void*)k_syrk_step, hipFuncAttributeMaxDynamicSharedMemorySize, STEP_LDS);
     (void)hipFuncSetAttribute((const void*)k_trtri_diag, hipFuncAttributeMaxDynamicSharedMemorySize, TRTRI_LDS);
     g_attr_done = true;
 }
@@ -972,6 +1105,16 @@ void launch_syrk_trail(double* A, int ld, int kb, int nt, bool skip_next_diag, h
     const int first = skip_next_diag ? 1 : 0;          // tile 0 = (kb+1, kb+1), done by launch_syrk_diag
     if (tri_count(m) - first <= 0) return;
     hipLaunchKernelGGL(k_syrk_trail, dim3(tri_count(m) - first), dim3(256), 0, s, A, ld, kb, first);
+}
+
+void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* logdet_part, unsigned* tickets,
+                      hipStream_t s)
+{
+    const int m = nt - kb - 1;
+    if (m <= 0) return;
+    set_big_lds();
+    hipLaunchKernelGGL(k_syrk_step, dim3(NDIAGWG + tri_count(m) - 1), dim3(256), STEP_LDS, s, A, ld, kb, d16,
+                       logdet_part, tickets);
 }
 
 void launch_syrk_diag(double* A, int ld, int kb, hipStream_t s)

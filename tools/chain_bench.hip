@@ -1,0 +1,72 @@
+// chain_bench.hip -- times the latency-critical kernels of the Cholesky chain alone (potf2, strip TRSM,
+// next-diagonal update) and prints in-kernel cycle stamps of potf2.  Diagnostic build: -DCUGP_STAMPS.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DCUGP_STAMPS -I cugp_amd/csrc tools/chain_bench.hip -o tools/bin/chain_bench
+#include "../cugp_amd/csrc/kernels.hip"
+
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+using namespace cugp;
+
+static float timeit(void (*fn)(void*), void* ctx, int reps)
+{
+    hipEvent_t a, b;
+    hipEventCreate(&a); hipEventCreate(&b);
+    fn(ctx);
+    hipDeviceSynchronize();
+    hipEventRecord(a);
+    for (int i = 0; i < reps; i++) fn(ctx);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    return ms * 1e3f / reps;
+}
+
+struct Ctx { double *A, *A0, *d16, *ld; int n, nt; };
+
+int main()
+{
+    setvbuf(stdout, NULL, _IONBF, 0);
+    const int nt = 16, n = nt * TILE;
+    std::vector<double> h((size_t)n * n);
+    srand(1);
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j <= i; j++) {
+            double v = (rand() / (double)RAND_MAX - 0.5) * 0.01;
+            if (i == j) v = 4.0 + v;
+            h[(size_t)i * n + j] = h[(size_t)j * n + i] = v;
+        }
+    Ctx c; c.n = n; c.nt = nt;
+    hipMalloc(&c.A, h.size() * 8); hipMalloc(&c.A0, h.size() * 8);
+    hipMalloc(&c.d16, (size_t)nt * 8 * 256 * 8); hipMalloc(&c.ld, nt * 8);
+    hipMemcpy(c.A0, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+    hipMemcpy(c.A, c.A0, h.size() * 8, hipMemcpyDeviceToDevice);
+
+    auto potf2 = [](void* p) { Ctx* c = (Ctx*)p; hipMemcpyAsync(c->A, c->A0, (size_t)TILE * c->n * 8, hipMemcpyDeviceToDevice, 0); launch_potf2(c->A, c->n, 0, c->d16, c->ld, 0); };
+    auto copy_only = [](void* p) { Ctx* c = (Ctx*)p; hipMemcpyAsync(c->A, c->A0, (size_t)TILE * c->n * 8, hipMemcpyDeviceToDevice, 0); };
+    float t_copy = timeit(copy_only, &c, 50);
+    float t_potf2 = timeit(potf2, &c, 50);
+    printf("potf2 (128x128 diagonal block): %.2f us (incl. %.2f us restore copy)\n", t_potf2, t_copy);
+    unsigned long long st[64];
+    hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof st);
+    printf("  stamps (cycles): load %llu | micro_factor0 %llu\n", st[1] - st[0], st[2] - st[1]);
+    for (int jb = 0; jb < 7; jb++)
+        printf("  jb=%d: wait+subst(B) %llu  diag-update %llu  micro_factor %llu\n", jb,
+               st[3 + 3 * jb] - (jb ? st[5 + 3 * (jb - 1)] : st[2]), st[4 + 3 * jb] - st[3 + 3 * jb],
+               st[5 + 3 * jb] - st[4 + 3 * jb]);
+    printf("  tail wait %llu | store+last inverse %llu | logdet %llu | total %llu cycles\n", st[30] - st[23],
+           st[31] - st[30], st[32] - st[31], st[32] - st[0]);
+
+    auto trsm = [](void* p) { Ctx* c = (Ctx*)p; launch_trsm_strips(c->A, c->d16, c->n, 0, c->nt, 0); };
+    printf("trsm_strips (%d strips): %.2f us\n", (nt - 1) * 8, timeit(trsm, &c, 50));
+    auto sd = [](void* p) { Ctx* c = (Ctx*)p; launch_syrk_diag(c->A, c->n, 0, 0); };
+    printf("syrk_diag: %.2f us\n", timeit(sd, &c, 50));
+    auto st1 = [](void* p) { Ctx* c = (Ctx*)p; launch_syrk_trail(c->A, c->n, 0, c->nt, true, 0); };
+    printf("syrk_trail (%d tiles): %.2f us\n", 15 * 16 / 2 - 1, timeit(st1, &c, 20));
+    auto st2 = [](void* p) { Ctx* c = (Ctx*)p; launch_syrk_trail(c->A, c->n, 13, c->nt, false, 0); };
+    printf("syrk_trail (3 tiles): %.2f us\n", timeit(st2, &c, 20));
+    auto empty = [](void* p) { Ctx* c = (Ctx*)p; launch_trsv_lower(c->A, c->A, c->n, 0, c->A, c->A, 0); };
+    (void)empty;
+    return 0;
+}
