@@ -54,7 +54,7 @@ struct cugp_gp {
     hipStream_t chain = nullptr;    // ... except the diagonal-block chain of the factorisation (high priority)
     std::vector<hipEvent_t> ev_p, ev_r;   // P[k]: diagonal block k factored; R[k]: panel k solved (R[nt]: inputs ready)
     double *dX = nullptr, *dy = nullptr, *dA = nullptr, *dT = nullptr, *dU = nullptr, *dKinv = nullptr;
-    double *dz = nullptr, *dalpha = nullptr, *dw = nullptr, *d16 = nullptr, *dlogdet = nullptr, *dpart = nullptr;
+    double *dz = nullptr, *dalpha = nullptr, *dw = nullptr, *d16 = nullptr, *dlogdet = nullptr, *dpart = nullptr, *d64 = nullptr;
     double* dout = nullptr;
     unsigned* dtickets = nullptr;  // one arrival counter per factorisation step (k_syrk_step)
     double* hout = nullptr;        // pinned, 8 doubles
@@ -135,12 +135,12 @@ int enqueue_potrf(cugp_gp* g)
     hipStream_t m = g->stream;
     const int nt = g->nt, ld = g->npad;
     HIPCHK(hipMemsetAsync(g->dtickets, 0, (size_t)nt * sizeof(unsigned), m));
-    launch_potf2(g->dA, ld, 0, g->d16, g->dlogdet, m);
+    launch_potf2(g->dA, ld, 0, g->d16, g->d64, g->dlogdet, m);
     for (int kb = 0; kb + 1 < nt; kb++) {
-        launch_trsm_strips(g->dA, g->d16, ld, kb, nt, m);
+        launch_trsm_inv64(g->dA, g->d64, ld, kb, nt, m);
         const bool ev = g->prof >= 2 && g->kev_used + 2 <= (int)g->kev.size();
         if (ev) HIPCHK(hipEventRecord(g->kev[g->kev_used], m));
-        launch_syrk_step(g->dA, ld, kb, nt, g->d16, g->dlogdet, g->dtickets, m);
+        launch_syrk_step(g->dA, ld, kb, nt, g->d16, g->d64, g->dlogdet, g->dtickets, m);
         if (ev) {
             HIPCHK(hipEventRecord(g->kev[g->kev_used + 1], m));
             g->kev_used += 2;
@@ -282,6 +282,7 @@ int cugp_create(int n, int d, int device, cugp_gp** out)
     if (e == hipSuccess) e = hipMalloc((void**)&g->dalpha, (size_t)g->npad * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&g->dw, (size_t)g->npad * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&g->d16, (size_t)g->nt * 8 * 256 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&g->d64, (size_t)g->nt * 8192 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&g->dlogdet, (size_t)g->nt * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&g->dpart, (size_t)g->nblocks_trace * 3 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&g->dout, 8 * sizeof(double));
@@ -304,7 +305,7 @@ int cugp_destroy(cugp_gp* g)
     if (g->stream) (void)hipStreamSynchronize(g->stream);
     if (g->chain) (void)hipStreamSynchronize(g->chain);
     double* bufs[] = {g->dX, g->dy, g->dA, g->dT, g->dU, g->dKinv, g->dz, g->dalpha, g->dw, g->d16, g->dlogdet,
-                      g->dpart, g->dout};
+                      g->dpart, g->dout, g->d64};
     for (double* p : bufs)
         if (p) (void)hipFree(p);
     if (g->dtickets) (void)hipFree(g->dtickets);

@@ -22,7 +22,9 @@ void launch_kcross(const double* X, int n, int d, int npad, const double* Xt, in
                    HyperScalars h, double* Ks, hipStream_t s);
 
 // ---- blocked right-looking Cholesky (N4) on the lower triangle of A (npad x npad, ld = npad) ----
-void launch_potf2(double* A, int ld, int kb, double* d16, double* logdet_part, hipStream_t s);
+// d16: 16x16 diagonal inverses [nt][8][256]; d64: the two 64x64 diagonal inverses of each block [nt][2][4096]
+void launch_potf2(double* A, int ld, int kb, double* d16, double* d64, double* logdet_part, hipStream_t s);
+void launch_trsm_inv64(double* A, const double* d64, int ld, int kb, int nt, hipStream_t s);     // 3-phase, 64x64 inverses
 void launch_trtri_diag(const double* A, int ld, int kb, int nblocks, const double* d16, double* T, double* U,
                        hipStream_t s);
 void launch_trsm_panel(double* A, const double* T, int ld, int kb, int nt, hipStream_t s);   // L21 = A21 T11^T (GEMM form)
@@ -30,8 +32,8 @@ void launch_trsm_strips(double* A, const double* d16, int ld, int kb, int nt, hi
 void launch_syrk_trail(double* A, int ld, int kb, int nt, bool skip_next_diag, hipStream_t s);
 void launch_syrk_diag(double* A, int ld, int kb, hipStream_t s);
 // trailing update of step kb fused with the factorisation of diagonal block kb+1 (tickets[kb] must be 0)
-void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* logdet_part, unsigned* tickets,
-                      hipStream_t s);    // tile (kb+1,kb+1) only, fine grained
+void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* d64, double* logdet_part,
+                      unsigned* tickets, hipStream_t s);    // tile (kb+1,kb+1) only, fine grained
 
 // ---- triangular inverse by recursive doubling (N7) and K^-1 = U U^T (N8) ----
 void launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, int s, int step, hipStream_t st);

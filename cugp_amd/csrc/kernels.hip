@@ -38,6 +38,13 @@ constexpr int OPER = (BK / 2) * PLANE;       // bytes per operand per stage  (16
 constexpr int STAGE = 2 * OPER;              // A + B
 constexpr int GEMM_LDS = 2 * STAGE;          // double buffered: 64 KiB
 
+// diagonal-block kernels work on 16x16 micro tiles (one MFMA tile)
+constexpr int MT = 16;                             // micro tile (one MFMA tile)
+constexpr int MTS = MT * (MT + 1);                 // doubles per LDS micro tile, rows padded to 17
+constexpr int NMT = TILE / MT;                     // 8 micro tiles per edge
+constexpr int NLT = NMT * (NMT + 1) / 2;           // 36 lower micro tiles
+constexpr int POTF2_LDS = (NLT * MTS + TILE) * 8;  // tiles + 1/L_ii  = 79360 B
+
 __device__ __forceinline__ int lds_slot(int row, int plane) { return ((row + plane) & (TILE - 1)) * 16; }
 
 // B-operand rows are stored permuted inside each 64-row half so that MFMA tiles n = 2p, 2p+1 of a
@@ -337,6 +344,62 @@ __global__ __launch_bounds__(256) void k_mfma_peak(double* sink, int iters)
 }
 
 // ------------------------------------------------------------------------------------------
+// panel solve with the two 64x64 diagonal inverses (T00, T11) of the factor block: per 16-row strip
+//   X0 = A0 T00^T ;  Z1 = A1 - X0 L10^T ;  X1 = Z1 T11^T
+// one workgroup (4 waves) per strip, wave w owns the 16-column tile w of each half; everything is kept
+// transposed so results in C/D layout are the next product's B operand (k = (lane>>4) + 4*reg); the
+// tiles the other waves need pass through 8 KiB of LDS.  <= 48 dependent MFMAs per wave (was 144).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_trsm_inv64(double* __restrict__ A, const double* __restrict__ d64,
+                                                    int ld, int kb)
+{
+    __shared__ double xbuf[4][4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int k0 = kb * TILE;
+    double* Arow = A + (size_t)(k0 + TILE + blockIdx.x * MT + c) * ld + k0;   // my row of the strip (as B operand / output)
+    const double* T00 = d64 + (size_t)kb * 8192;
+    const double* T11 = T00 + 4096;
+    const double* L10 = A + (size_t)(k0 + 64) * ld + k0;
+    const d4 zero4 = (d4){0.0, 0.0, 0.0, 0.0};
+
+    // phase 1: X0^T[w] = sum_{kt <= w} T00[w][kt] A0^T[kt]
+    d4 x0 = zero4;
+    for (int kt = 0; kt <= w; kt++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(T00[(w * MT + c) * 64 + kt * MT + g + 4 * r],
+                                                      Arow[kt * MT + g + 4 * r], x0, 0, 0, 0);
+    }
+    d4 z;
+#pragma unroll
+    for (int r = 0; r < 4; r++) { xbuf[w][r][lane] = x0[r]; z[r] = Arow[64 + w * MT + g + 4 * r]; }
+    __syncthreads();
+    // phase 2: Z1^T[w] = A1^T[w] - sum_kt L10[w][kt] X0^T[kt]
+#pragma unroll
+    for (int kt = 0; kt < 4; kt++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            z = __builtin_amdgcn_mfma_f64_16x16x4f64(-L10[(size_t)(w * MT + c) * ld + kt * MT + g + 4 * r],
+                                                     xbuf[kt][r][lane], z, 0, 0, 0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; r++) { xbuf[w][r][lane] = z[r]; Arow[w * MT + g + 4 * r] = x0[r]; }
+    __syncthreads();
+    // phase 3: X1^T[w] = sum_{kt <= w} T11[w][kt] Z1^T[kt]
+    d4 x1 = zero4;
+    for (int kt = 0; kt <= w; kt++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(T11[(w * MT + c) * 64 + kt * MT + g + 4 * r], xbuf[kt][r][lane],
+                                                      x1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) Arow[64 + w * MT + g + 4 * r] = x1[r];
+}
+
+// ------------------------------------------------------------------------------------------
 // SE covariance build: 64x64 tile per 256-thread workgroup, 4x4 outputs per thread, X tiles in LDS
 // ------------------------------------------------------------------------------------------
 constexpr int KT = 64;      // kernel-build tile
@@ -456,11 +519,6 @@ constexpr int PLD = TILE + 1;                      // padded LDS row stride (dou
 constexpr int TRTRI_LDS = TILE * PLD * 8 + (TILE - 16) * 17 * 8;
 
 // ---- helpers for the diagonal block ------------------------------------------------------
-constexpr int MT = 16;                             // micro tile (one MFMA tile)
-constexpr int MTS = MT * (MT + 1);                 // doubles per LDS micro tile, rows padded to 17
-constexpr int NMT = TILE / MT;                     // 8 micro tiles per edge
-constexpr int NLT = NMT * (NMT + 1) / 2;           // 36 lower micro tiles
-constexpr int POTF2_LDS = (NLT * MTS + TILE) * 8;  // tiles + 1/L_ii  = 79360 B
 
 __device__ __forceinline__ int mt_off(int bi, int bj) { return (bi * (bi + 1) / 2 + bj) * MTS; }
 
@@ -588,9 +646,38 @@ __device__ unsigned long long g_stamps[64];
 #define STAMP(i)
 #endif
 
+// one MFMA 16x16x16 product on LDS micro tiles, "NN": acc += A(tile a)[row][k] * B(tile b)[k][col]
+__device__ __forceinline__ d4 micro_mma_nn(const double* __restrict__ a, const double* __restrict__ b, d4 acc)
+{
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int s = 0; s < 4; s++)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[c * (MT + 1) + 4 * s + g], b[(4 * s + g) * (MT + 1) + c], acc, 0,
+                                                   0, 0);
+    return acc;
+}
+
+// acc -= A(tile a)[row][k] * W[k][col] where W is a previous MFMA result held in registers (C/D layout):
+// register r of lane (col, g) is W[g + 4r][col], i.e. already the B operand for k = g + 4r
+__device__ __forceinline__ d4 micro_mma_acc_b(const double* __restrict__ a, d4 w, d4 acc)
+{
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[c * (MT + 1) + g + 4 * r], w[r], acc, 0, 0, 0);
+    return acc;
+}
+
+__device__ __forceinline__ void micro_store(double* __restrict__ tile, d4 v)
+{
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < 4; r++) tile[(g + 4 * r) * (MT + 1) + c] = v[r];
+}
+
 __device__ __forceinline__ void potf2_body(double* __restrict__ Ab, int ld, double* __restrict__ d16blk,
-                                           double* __restrict__ logdet_out, double* __restrict__ sm,
-                                           double* __restrict__ red)
+                                           double* __restrict__ d64blk, double* __restrict__ logdet_out,
+                                           double* __restrict__ sm, double* __restrict__ red)
 {
     double* rinv = sm + NLT * MTS;                          // 1 / L_ii, 128 entries
     const int t = threadIdx.x, wave = t >> 6;
@@ -669,15 +756,58 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ Ab, int ld, doub
     }
     if (t == 0) *logdet_out = red[0];
     STAMP(32);
+
+    // ---- inverses of the two 64x64 diagonal sub-blocks, in place over the factor (already stored) ----
+    // used by the panel solve: 3 short MFMA phases per strip instead of a 144-long dependent chain.
+    {   // 16x16 inverses (written to d16 above by this workgroup; the barriers above order them) -> diagonal tiles
+        const int r = t >> 4, c = t & 15;
+#pragma unroll
+        for (int jb = 0; jb < NMT; jb++) sm[mt_off(jb, jb) + r * (MT + 1) + c] = d16blk[jb * (MT * MT) + t];
+    }
+    __syncthreads();
+    const d4 zero4 = (d4){0.0, 0.0, 0.0, 0.0};
+    {   // 16 -> 32: pair p = wave: T21 = -T_B (L21 T_A)
+        const int a = 2 * wave, b = 2 * wave + 1;
+        d4 w = micro_mma_nn(sm + mt_off(b, a), sm + mt_off(a, a), zero4);
+        d4 t21 = micro_mma_acc_b(sm + mt_off(b, b), w, zero4);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        micro_store(sm + mt_off(b, a), t21);
+    }
+    __syncthreads();
+    {   // 32 -> 64: 64-block h = wave >> 1, column bj = wave & 1 of its lower-left 2x2 micro tiles
+        const int h = wave >> 1, bj = wave & 1, a0 = 4 * h, b0 = 4 * h + 2;
+        d4 w0 = zero4, w1 = zero4;                      // W(kb', bj) = sum_{jb' >= bj} C(kb', jb') T_A(jb', bj)
+        for (int jp = bj; jp < 2; jp++) {
+            w0 = micro_mma_nn(sm + mt_off(b0, a0 + jp), sm + mt_off(a0 + jp, a0 + bj), w0);
+            w1 = micro_mma_nn(sm + mt_off(b0 + 1, a0 + jp), sm + mt_off(a0 + jp, a0 + bj), w1);
+        }
+        __syncthreads();                                // every wave has read its C tiles
+        d4 t0 = micro_mma_acc_b(sm + mt_off(b0, b0), w0, zero4);                // bi = 0: k' = 0
+        d4 t1 = micro_mma_acc_b(sm + mt_off(b0 + 1, b0), w0, zero4);            // bi = 1: k' = 0, 1
+        t1 = micro_mma_acc_b(sm + mt_off(b0 + 1, b0 + 1), w1, t1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        micro_store(sm + mt_off(b0, a0 + bj), t0);
+        micro_store(sm + mt_off(b0 + 1, a0 + bj), t1);
+    }
+    __syncthreads();
+    {   // the two inverses to global, row-major 64x64 each (micro tiles above the diagonal are never read)
+        const int r = t >> 4, c = t & 15;
+        for (int h = 0; h < 2; h++)
+            for (int bi = 0; bi < 4; bi++)
+                for (int bj = 0; bj <= bi; bj++)
+                    d64blk[(size_t)h * 4096 + (bi * MT + r) * 64 + bj * MT + c] =
+                        sm[mt_off(4 * h + bi, 4 * h + bj) + r * (MT + 1) + c];
+    }
+    STAMP(33);
 }
 
 __global__ __launch_bounds__(256) void k_potf2(double* __restrict__ A, int ld, int kb, double* __restrict__ d16,
-                                               double* __restrict__ logdet_part)
+                                               double* __restrict__ d64, double* __restrict__ logdet_part)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ double red[TILE];
-    potf2_body(A + (size_t)kb * TILE * ld + kb * TILE, ld, d16 + (size_t)kb * NMT * (MT * MT), logdet_part + kb, sm,
-               red);
+    potf2_body(A + (size_t)kb * TILE * ld + kb * TILE, ld, d16 + (size_t)kb * NMT * (MT * MT),
+               d64 + (size_t)kb * 8192, logdet_part + kb, sm, red);
 }
 
 // one 16x16 micro tile of A(kb+1,kb+1) -= L(kb+1,kb) L(kb+1,kb)^T, by one wave, operands straight from L2
@@ -721,7 +851,8 @@ constexpr int NDIAGWG = NLT / 4;                      // 9 workgroups x 4 waves 
 constexpr int STEP_LDS = POTF2_LDS;                   // >= GEMM_LDS; two such workgroups still fit one CU
 
 __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, int ld, int kb,
-                                                      double* __restrict__ d16, double* __restrict__ logdet_part,
+                                                      double* __restrict__ d16, double* __restrict__ d64,
+                                                      double* __restrict__ logdet_part,
                                                       unsigned* __restrict__ tickets)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -745,8 +876,8 @@ __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, in
         }
         __syncthreads();
         const int kn = kb + 1;
-        potf2_body(A + (size_t)kn * TILE * ld + kn * TILE, ld, d16 + (size_t)kn * NMT * (MT * MT), logdet_part + kn,
-                   sm, red);
+        potf2_body(A + (size_t)kn * TILE * ld + kn * TILE, ld, d16 + (size_t)kn * NMT * (MT * MT),
+                   d64 + (size_t)kn * 8192, logdet_part + kn, sm, red);
         return;
     }
     int ti, tj;
@@ -1072,10 +1203,17 @@ static void set_big_lds()
     g_attr_done = true;
 }
 
-void launch_potf2(double* A, int ld, int kb, double* d16, double* logdet_part, hipStream_t s)
+void launch_potf2(double* A, int ld, int kb, double* d16, double* d64, double* logdet_part, hipStream_t s)
 {
     set_big_lds();
-    hipLaunchKernelGGL(k_potf2, dim3(1), dim3(256), POTF2_LDS, s, A, ld, kb, d16, logdet_part);
+    hipLaunchKernelGGL(k_potf2, dim3(1), dim3(256), POTF2_LDS, s, A, ld, kb, d16, d64, logdet_part);
+}
+
+void launch_trsm_inv64(double* A, const double* d64, int ld, int kb, int nt, hipStream_t s)
+{
+    const int nstrips = (nt - kb - 1) * (TILE / MT);
+    if (nstrips <= 0) return;
+    hipLaunchKernelGGL(k_trsm_inv64, dim3(nstrips), dim3(256), 0, s, A, d64, ld, kb);
 }
 
 void launch_trtri_diag(const double* A, int ld, int kb, int nblocks, const double* d16, double* T, double* U,
@@ -1107,13 +1245,13 @@ void launch_syrk_trail(double* A, int ld, int kb, int nt, bool skip_next_diag, h
     hipLaunchKernelGGL(k_syrk_trail, dim3(tri_count(m) - first), dim3(256), 0, s, A, ld, kb, first);
 }
 
-void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* logdet_part, unsigned* tickets,
-                      hipStream_t s)
+void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* d64, double* logdet_part,
+                      unsigned* tickets, hipStream_t s)
 {
     const int m = nt - kb - 1;
     if (m <= 0) return;
     set_big_lds();
-    hipLaunchKernelGGL(k_syrk_step, dim3(NDIAGWG + tri_count(m) - 1), dim3(256), STEP_LDS, s, A, ld, kb, d16,
+    hipLaunchKernelGGL(k_syrk_step, dim3(NDIAGWG + tri_count(m) - 1), dim3(256), STEP_LDS, s, A, ld, kb, d16, d64,
                        logdet_part, tickets);
 }
 

@@ -23,7 +23,7 @@ static float timeit(void (*fn)(void*), void* ctx, int reps)
     return ms * 1e3f / reps;
 }
 
-struct Ctx { double *A, *A0, *d16, *ld; int n, nt; };
+struct Ctx { double *A, *A0, *d16, *d64, *ld; int n, nt; };
 
 int main()
 {
@@ -39,11 +39,11 @@ int main()
         }
     Ctx c; c.n = n; c.nt = nt;
     hipMalloc(&c.A, h.size() * 8); hipMalloc(&c.A0, h.size() * 8);
-    hipMalloc(&c.d16, (size_t)nt * 8 * 256 * 8); hipMalloc(&c.ld, nt * 8);
+    hipMalloc(&c.d16, (size_t)nt * 8 * 256 * 8); hipMalloc(&c.d64, (size_t)nt * 8192 * 8); hipMalloc(&c.ld, nt * 8);
     hipMemcpy(c.A0, h.data(), h.size() * 8, hipMemcpyHostToDevice);
     hipMemcpy(c.A, c.A0, h.size() * 8, hipMemcpyDeviceToDevice);
 
-    auto potf2 = [](void* p) { Ctx* c = (Ctx*)p; hipMemcpyAsync(c->A, c->A0, (size_t)TILE * c->n * 8, hipMemcpyDeviceToDevice, 0); launch_potf2(c->A, c->n, 0, c->d16, c->ld, 0); };
+    auto potf2 = [](void* p) { Ctx* c = (Ctx*)p; hipMemcpyAsync(c->A, c->A0, (size_t)TILE * c->n * 8, hipMemcpyDeviceToDevice, 0); launch_potf2(c->A, c->n, 0, c->d16, c->d64, c->ld, 0); };
     auto copy_only = [](void* p) { Ctx* c = (Ctx*)p; hipMemcpyAsync(c->A, c->A0, (size_t)TILE * c->n * 8, hipMemcpyDeviceToDevice, 0); };
     float t_copy = timeit(copy_only, &c, 50);
     float t_potf2 = timeit(potf2, &c, 50);
@@ -55,11 +55,13 @@ int main()
         printf("  jb=%d: wait+subst(B) %llu  diag-update %llu  micro_factor %llu\n", jb,
                st[3 + 3 * jb] - (jb ? st[5 + 3 * (jb - 1)] : st[2]), st[4 + 3 * jb] - st[3 + 3 * jb],
                st[5 + 3 * jb] - st[4 + 3 * jb]);
-    printf("  tail wait %llu | store+last inverse %llu | logdet %llu | total %llu cycles\n", st[30] - st[23],
-           st[31] - st[30], st[32] - st[31], st[32] - st[0]);
+    printf("  tail wait %llu | store+last inverse %llu | logdet %llu | 64x64 inverses %llu | total %llu cycles\n",
+           st[30] - st[23], st[31] - st[30], st[32] - st[31], st[33] - st[32], st[33] - st[0]);
 
     auto trsm = [](void* p) { Ctx* c = (Ctx*)p; launch_trsm_strips(c->A, c->d16, c->n, 0, c->nt, 0); };
     printf("trsm_strips (%d strips): %.2f us\n", (nt - 1) * 8, timeit(trsm, &c, 50));
+    auto trsm2 = [](void* p) { Ctx* c = (Ctx*)p; launch_trsm_inv64(c->A, c->d64, c->n, 0, c->nt, 0); };
+    printf("trsm_inv64 (%d strips): %.2f us\n", (nt - 1) * 8, timeit(trsm2, &c, 50));
     auto sd = [](void* p) { Ctx* c = (Ctx*)p; launch_syrk_diag(c->A, c->n, 0, 0); };
     printf("syrk_diag: %.2f us\n", timeit(sd, &c, 50));
     auto st1 = [](void* p) { Ctx* c = (Ctx*)p; launch_syrk_trail(c->A, c->n, 0, c->nt, true, 0); };
