@@ -180,6 +180,29 @@ def test_big_golden_4096(gp_mod, sine):
         assert vec_close(gr, c["grad"]), (gr, c["grad"])
 
 
+def test_big_golden_8192(gp_mod):
+    """The metric configuration itself: siproper_9192_10, first 8192 rows, hp = 0.5 (ver2/main.cpp:178-181):
+    the reference's serial C++ needed ~30 min for this log-likelihood (and ~2 h for the gradient)."""
+    import json, os
+    g = os.path.join(os.path.dirname(__file__), "golden")
+    p, d = os.path.join(g, "golden_big_8192.json"), os.path.join(g, "data_siproper_9192.npz")
+    if not (os.path.exists(p) and os.path.exists(d)):
+        pytest.skip("golden_big_8192.json not generated")
+    c = json.load(open(p))["cases"]["siproper_8192"]
+    z = np.load(d)
+    X, y = np.ascontiguousarray(z["X"][:8192]), np.ascontiguousarray(z["y"][:8192])
+    gp_ = gp_mod.Covsum(8192, 10)
+    gp_.set_loghyperparam(c["hp"])
+    ll, gr = gp_.loglik_grad(X, y)
+    assert ll_close(ll, c["ll"]), (ll, c["ll"])
+    assert ll_close(gp_.compute_loglikelihood(), c["ll"])
+    if "grad" in c:
+        assert vec_close(gr, c["grad"]), (gr, c["grad"])
+    # held-out rows 8192..9191 of the same file (the reference's testing_phase split)
+    m, v = gp_.compute_test_means_and_variances(X, y, z["X"][8192:8192 + 1000])
+    assert np.all(np.isfinite(m)) and np.all(v > 0)
+
+
 # ------------------------------------------------------------------ optimiser end to end
 def test_cg_solve_matches_reference_trace(gp_mod, si128, golden_si128, ref_log):
     """Covsum::cg_solve from hp=1.5 on si128: the run the reference committed as ver2/REF."""
