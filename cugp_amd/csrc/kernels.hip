@@ -33,10 +33,15 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 // fp64 MFMA tile product
 // ------------------------------------------------------------------------------------------
 constexpr int BK = 16;                       // k depth per LDS stage
-constexpr int PLANE = TILE * 16;             // bytes per k-pair plane (128 rows x 2 doubles)
-constexpr int OPER = (BK / 2) * PLANE;       // bytes per operand per stage  (16 KiB)
-constexpr int STAGE = 2 * OPER;              // A + B
-constexpr int GEMM_LDS = 2 * STAGE;          // double buffered: 64 KiB
+// geometry of a tile product whose waves hold WM x WM MFMA tiles each (block edge 32*WM: 128 or 64)
+template <int WM> struct Geo {
+    static constexpr int BT = 32 * WM;               // block tile edge
+    static constexpr int PLANE = BT * 16;            // bytes per k-pair plane (BT rows x 2 doubles)
+    static constexpr int OPER = (BK / 2) * PLANE;    // bytes per operand per stage
+    static constexpr int STAGE = 2 * OPER;           // A + B
+    static constexpr int LDS = 2 * STAGE;            // double buffered: 64 KiB (WM=4) / 32 KiB (WM=2)
+};
+constexpr int GEMM_LDS = Geo<4>::LDS;
 
 // diagonal-block kernels work on 16x16 micro tiles (one MFMA tile)
 constexpr int MT = 16;                             // micro tile (one MFMA tile)
@@ -45,49 +50,53 @@ constexpr int NMT = TILE / MT;                     // 8 micro tiles per edge
 constexpr int NLT = NMT * (NMT + 1) / 2;           // 36 lower micro tiles
 constexpr int POTF2_LDS = (NLT * MTS + TILE) * 8;  // tiles + 1/L_ii  = 79360 B
 
-__device__ __forceinline__ int lds_slot(int row, int plane) { return ((row + plane) & (TILE - 1)) * 16; }
+template <int WM>
+__device__ __forceinline__ int lds_slot(int row, int plane) { return ((row + plane) & (32 * WM - 1)) * 16; }
 
-// B-operand rows are stored permuted inside each 64-row half so that MFMA tiles n = 2p, 2p+1 of a
-// wave produce ADJACENT output columns in one lane (16-byte global accesses in the epilogue) while
-// the fragment reads stay 256 contiguous bytes: tile row R -> LDS position bpos(R).
+// B-operand rows are stored permuted inside each wave's column range so that MFMA tiles n = 2p, 2p+1
+// of a wave produce ADJACENT output columns in one lane (16-byte global accesses in the epilogue)
+// while the fragment reads stay 256 contiguous bytes: tile row R -> LDS position bpos(R).
+template <int WM>
 __device__ __forceinline__ int bpos(int R)
 {
-    const int h = R & 64, q = R & 63;
-    return h + (((q >> 5) * 2 + (q & 1)) * 16) + ((q & 31) >> 1);
+    const int q = R & (16 * WM - 1);
+    return (R - q) + (((q >> 5) * 2 + (q & 1)) * 16) + ((q & 31) >> 1);
 }
 
 // acc[m][n] += (NEGA ? -1 : 1) * A(i0.., kbeg..kend) * B(j0.., kbeg..kend)^T ; Ag -> A[i0][0], Bg -> B[j0][0];
-// kbeg, kend multiples of BK.  All 256 threads must call (barriers inside).
-template <bool NEGA>
+// kbeg, kend multiples of BK.  All 256 threads must call (barriers inside).  WM (deduced from acc) is the
+// number of 16x16 MFMA tiles per wave per dimension: 4 -> 128x128 block, 2 -> 64x64 block.
+template <bool NEGA, int WM>
 __device__ __forceinline__ void tile_nt(const double* __restrict__ Ag, int lda, const double* __restrict__ Bg,
-                                        int ldb, int kbeg, int kend, d4 (&acc)[4][4], char* smem)
+                                        int ldb, int kbeg, int kend, d4 (&acc)[WM][WM], char* smem)
 {
+    typedef Geo<WM> G;
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wr = wave >> 1, wc = wave & 1;
 
-    // staging map: 4 chunks of 16 B per operand per thread; 8 consecutive lanes cover one row's 128 B
+    // staging map: WM chunks of 16 B per operand per thread; 8 consecutive lanes cover one row's 128 B
     const int srow = t >> 3, skp = t & 7;                 // + 32 rows per q
     const double* ag = Ag + (size_t)srow * lda + 2 * skp;
     const double* bg = Bg + (size_t)srow * ldb + 2 * skp;
-    d2 ra[4], rb[4];
-    int wa[4], wb[4];                                     // LDS byte offsets of my staging chunks
+    d2 ra[WM], rb[WM];
+    int wa[WM], wb[WM];                                   // LDS byte offsets of my staging chunks
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        wa[q] = skp * PLANE + lds_slot(srow + 32 * q, skp);
-        wb[q] = OPER + skp * PLANE + lds_slot(bpos(srow + 32 * q), skp);
+    for (int q = 0; q < WM; q++) {
+        wa[q] = skp * G::PLANE + lds_slot<WM>(srow + 32 * q, skp);
+        wb[q] = G::OPER + skp * G::PLANE + lds_slot<WM>(bpos<WM>(srow + 32 * q), skp);
     }
 
     const int nk = (kend - kbeg) / BK;
     if (nk <= 0) return;
 
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < WM; q++) {
         ra[q] = *(const d2*)(ag + (size_t)(32 * q) * lda + kbeg);
         rb[q] = *(const d2*)(bg + (size_t)(32 * q) * ldb + kbeg);
     }
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
+    for (int q = 0; q < WM; q++) {
         *(d2*)(smem + wa[q]) = NEGA ? -ra[q] : ra[q];
         *(d2*)(smem + wb[q]) = rb[q];
     }
@@ -97,13 +106,13 @@ __device__ __forceinline__ void tile_nt(const double* __restrict__ Ag, int lda, 
     const int fhi = fk >> 1, flo = (fk & 1) * 8;
 
     for (int kt = 0; kt < nk; kt++) {
-        char* cur = smem + (kt & 1) * STAGE;
-        char* nxt = smem + ((kt + 1) & 1) * STAGE;
+        char* cur = smem + (kt & 1) * G::STAGE;
+        char* nxt = smem + ((kt + 1) & 1) * G::STAGE;
         const bool more = (kt + 1 < nk);
         if (more) {
             const int k = kbeg + (kt + 1) * BK;
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < WM; q++) {
                 ra[q] = *(const d2*)(ag + (size_t)(32 * q) * lda + k);
                 rb[q] = *(const d2*)(bg + (size_t)(32 * q) * ldb + k);
             }
@@ -111,21 +120,22 @@ __device__ __forceinline__ void tile_nt(const double* __restrict__ Ag, int lda, 
 #pragma unroll
         for (int kk = 0; kk < BK / 4; kk++) {
             const int p = kk * 2 + fhi;
-            double a[4], b[4];
+            double a[WM], b[WM];
 #pragma unroll
-            for (int m = 0; m < 4; m++) {
-                a[m] = *(const double*)(cur + p * PLANE + lds_slot(wr * 64 + m * 16 + fr, p) + flo);
-                b[m] = *(const double*)(cur + OPER + p * PLANE + lds_slot(wc * 64 + m * 16 + fr, p) + flo);
+            for (int m = 0; m < WM; m++) {
+                a[m] = *(const double*)(cur + p * G::PLANE + lds_slot<WM>(wr * 16 * WM + m * 16 + fr, p) + flo);
+                b[m] = *(const double*)(cur + G::OPER + p * G::PLANE + lds_slot<WM>(wc * 16 * WM + m * 16 + fr, p) +
+                                        flo);
             }
 #pragma unroll
-            for (int m = 0; m < 4; m++)
+            for (int m = 0; m < WM; m++)
 #pragma unroll
-                for (int n = 0; n < 4; n++)
+                for (int n = 0; n < WM; n++)
                     acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
         }
         if (more) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
+            for (int q = 0; q < WM; q++) {
                 *(d2*)(nxt + wa[q]) = NEGA ? -ra[q] : ra[q];
                 *(d2*)(nxt + wb[q]) = rb[q];
             }
@@ -134,31 +144,33 @@ __device__ __forceinline__ void tile_nt(const double* __restrict__ Ag, int lda, 
     }
 }
 
-__device__ __forceinline__ void acc_zero(d4 (&acc)[4][4])
+template <int WM>
+__device__ __forceinline__ void acc_zero(d4 (&acc)[WM][WM])
 {
 #pragma unroll
-    for (int m = 0; m < 4; m++)
+    for (int m = 0; m < WM; m++)
 #pragma unroll
-        for (int n = 0; n < 4; n++) acc[m][n] = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int n = 0; n < WM; n++) acc[m][n] = (d4){0.0, 0.0, 0.0, 0.0};
 }
 
 // accumulator element (m,n,r) of this lane is C[row][col]: f64 16x16x4 C/D map (col = lane&15,
 // row = (lane>>4) + 4*r inside a 16x16 tile) composed with the B-row permutation above, so tiles
 // n = 2p and 2p+1 hold columns 2*(lane&15) and 2*(lane&15)+1 of the 32-column group p.
-#define ACC_ROW(m, r) (wr * 64 + (m) * 16 + (lane >> 4) + 4 * (r))
-#define ACC_COL2(np) (wc * 64 + (np) * 32 + 2 * (lane & 15))
+#define ACC_ROW(m, r) (wr * 16 * WM + (m) * 16 + (lane >> 4) + 4 * (r))
+#define ACC_COL2(np) (wc * 16 * WM + (np) * 32 + 2 * (lane & 15))
 
 // acc = C   (the K loop then accumulates straight onto it: no read-modify-write epilogue)
-__device__ __forceinline__ void tile_load(const double* __restrict__ C, int ldc, d4 (&acc)[4][4])
+template <int WM>
+__device__ __forceinline__ void tile_load(const double* __restrict__ C, int ldc, d4 (&acc)[WM][WM])
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
 #pragma unroll
-    for (int m = 0; m < 4; m++)
+    for (int m = 0; m < WM; m++)
 #pragma unroll
         for (int r = 0; r < 4; r++)
 #pragma unroll
-            for (int np = 0; np < 2; np++) {
+            for (int np = 0; np < WM / 2; np++) {
                 const d2 v = *(const d2*)(C + (size_t)ACC_ROW(m, r) * ldc + ACC_COL2(np));
                 acc[m][2 * np][r] = v[0];
                 acc[m][2 * np + 1][r] = v[1];
@@ -166,27 +178,31 @@ __device__ __forceinline__ void tile_load(const double* __restrict__ C, int ldc,
 }
 
 // C = alpha * acc
-__device__ __forceinline__ void tile_store(double* __restrict__ C, int ldc, const d4 (&acc)[4][4], double alpha)
+template <int WM>
+__device__ __forceinline__ void tile_store(double* __restrict__ C, int ldc, const d4 (&acc)[WM][WM], double alpha)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wr = wave >> 1, wc = wave & 1;
 #pragma unroll
-    for (int m = 0; m < 4; m++)
+    for (int m = 0; m < WM; m++)
 #pragma unroll
         for (int r = 0; r < 4; r++)
 #pragma unroll
-            for (int np = 0; np < 2; np++)
+            for (int np = 0; np < WM / 2; np++)
                 *(d2*)(C + (size_t)ACC_ROW(m, r) * ldc + ACC_COL2(np)) =
                     (d2){alpha * acc[m][2 * np][r], alpha * acc[m][2 * np + 1][r]};
 }
 
 // Ct[col][row] = alpha*acc  (transposed store).  The tile is turned through LDS (free after the K loop)
-// in two 64-row halves so that global stores are whole 512-byte runs; the LDS image [col][64 rows] is
-// XOR-swizzled on the row index so the accumulator-layout writes do not pile onto one bank.
-// All 256 threads must call.
-__device__ __forceinline__ void tile_store_t(double* __restrict__ Ct, int ldc, const d4 (&acc)[4][4], double alpha,
+// in two halves of 16*WM rows so that global stores are whole runs of that many doubles; the LDS image
+// [col][16*WM rows] is XOR-swizzled on the row index so the accumulator-layout writes do not pile onto
+// one bank.  All 256 threads must call.
+template <int WM>
+__device__ __forceinline__ void tile_store_t(double* __restrict__ Ct, int ldc, const d4 (&acc)[WM][WM], double alpha,
                                              char* smem)
 {
+    constexpr int RH = 16 * WM, BT = 32 * WM;            // rows per half, block edge
+    constexpr int LPC = RH / 2, CPP = 256 / LPC;         // lanes per column-row, column-rows per pass
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wr = wave >> 1, wc = wave & 1;
     double* sd = (double*)smem;
@@ -195,25 +211,24 @@ __device__ __forceinline__ void tile_store_t(double* __restrict__ Ct, int ldc, c
         __syncthreads();
         if (wr == h) {
 #pragma unroll
-            for (int m = 0; m < 4; m++)
+            for (int m = 0; m < WM; m++)
 #pragma unroll
-                for (int n = 0; n < 4; n++)
+                for (int n = 0; n < WM; n++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         const int col = ACC_COL2(n >> 1) + (n & 1);
                         const int rr = m * 16 + (lane >> 4) + 4 * r;
-                        sd[col * 64 + (rr ^ ((col >> 1) & 15))] = alpha * acc[m][n][r];
+                        sd[col * RH + (rr ^ ((col >> 1) & 15))] = alpha * acc[m][n][r];
                     }
         }
         __syncthreads();
-        // 8 column-rows per pass: 32 lanes x 2 doubles = one 64-row run
-        const int rr = (t & 31) * 2;
+        const int rr = (t % LPC) * 2;
 #pragma unroll
-        for (int pass = 0; pass < 16; pass++) {
-            const int col = pass * 8 + (t >> 5);
+        for (int pass = 0; pass < BT / CPP; pass++) {
+            const int col = pass * CPP + t / LPC;
             const int sw = (col >> 1) & 15;
-            const d2 v = (d2){sd[col * 64 + (rr ^ sw)], sd[col * 64 + ((rr + 1) ^ sw)]};
-            *(d2*)(Ct + (size_t)col * ldc + h * 64 + rr) = v;
+            const d2 v = (d2){sd[col * RH + (rr ^ sw)], sd[col * RH + ((rr + 1) ^ sw)]};
+            *(d2*)(Ct + (size_t)col * ldc + h * RH + rr) = v;
         }
     }
 }
@@ -272,14 +287,18 @@ __global__ __launch_bounds__(256, 2) void k_lauum(const double* __restrict__ U, 
 // ---- recursive-doubling inverse, one level.  Blocks of s tiles: [A 0; C B]^-1 = [TA 0; -TB C TA, TB].
 // step 1: Wt(tj in A, ti in B) = sum_{k in A, k >= tj} U[tj][k] * L[ti][k]   -> scratch in T's upper tiles
 // step 2: T(ti in B, tj in A) = -sum_{k in B, k <= ti} T[ti][k] * Wt[tj][k]   and U(tj,ti) = transpose
+template <int WM>
 __global__ __launch_bounds__(256, 2) void k_trtri_level(const double* __restrict__ L, double* __restrict__ T,
                                                         double* __restrict__ U, int ld, int nt, int s, int step)
 {
-    __shared__ __attribute__((aligned(16))) char smem[GEMM_LDS];
+    __shared__ __attribute__((aligned(16))) char smem[Geo<WM>::LDS];
+    constexpr int SUB = 4 / WM;                          // output sub-tiles per 128-tile edge (1 or 2)
+    constexpr int BT = 32 * WM;
+    const int blk = blockIdx.x / (SUB * SUB), sub = blockIdx.x % (SUB * SUB);
     const int npairs = (nt + 2 * s - 1) / (2 * s);      // last one may have a short (or empty) B
-    int p = blockIdx.x / (s * s);
+    int p = blk / (s * s);
     if (p > npairs - 1) p = npairs - 1;
-    int rem = blockIdx.x - p * s * s;
+    int rem = blk - p * s * s;
     const int a0 = 2 * p * s;                            // A = [a0, a0+s), B = [a0+s, min(a0+2s, nt))
     const int b0 = a0 + s;
     int sb = nt - b0;
@@ -289,17 +308,19 @@ __global__ __launch_bounds__(256, 2) void k_trtri_level(const double* __restrict
     const int ja = (step == 1) ? rem / sb : rem % s;
     const int ib = (step == 1) ? rem % sb : sb - 1 - rem / s;
     const int tj = a0 + ja, ti = b0 + ib;
-    d4 acc[4][4];
+    const int si = (sub / SUB) * BT, sj = (sub % SUB) * BT;     // offsets of my sub-tile inside the 128-tile
+    d4 acc[WM][WM];
     acc_zero(acc);
     if (step == 1) {
-        tile_nt<false>(U + (size_t)tj * TILE * ld, ld, L + (size_t)ti * TILE * ld, ld, tj * TILE, b0 * TILE, acc,
-                       smem);
-        tile_store(T + (size_t)tj * TILE * ld + ti * TILE, ld, acc, 1.0);
+        // Wt(tj, ti) rows in A's tile tj, columns in B's tile ti
+        tile_nt<false>(U + (size_t)(tj * TILE + si) * ld, ld, L + (size_t)(ti * TILE + sj) * ld, ld, tj * TILE,
+                       b0 * TILE, acc, smem);
+        tile_store(T + (size_t)(tj * TILE + si) * ld + ti * TILE + sj, ld, acc, 1.0);
     } else {
-        tile_nt<true>(T + (size_t)ti * TILE * ld, ld, T + (size_t)tj * TILE * ld, ld, b0 * TILE, (ti + 1) * TILE,
-                      acc, smem);
-        tile_store(T + (size_t)ti * TILE * ld + tj * TILE, ld, acc, 1.0);
-        tile_store_t(U + (size_t)tj * TILE * ld + ti * TILE, ld, acc, 1.0, smem);
+        tile_nt<true>(T + (size_t)(ti * TILE + si) * ld, ld, T + (size_t)(tj * TILE + sj) * ld, ld, b0 * TILE,
+                      (ti + 1) * TILE, acc, smem);
+        tile_store(T + (size_t)(ti * TILE + si) * ld + tj * TILE + sj, ld, acc, 1.0);
+        tile_store_t(U + (size_t)(tj * TILE + sj) * ld + ti * TILE + si, ld, acc, 1.0, smem);
     }
 }
 
@@ -1270,7 +1291,11 @@ void launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, i
         tiles += s * sb;
     }
     if (tiles <= 0) return;
-    hipLaunchKernelGGL(k_trtri_level, dim3(tiles), dim3(256), 0, st, L, T, U, ld, nt, s, step);
+    // few 128-tiles cannot fill 512 workgroup slots: use 64x64 output tiles (4x the parallelism) there
+    if (tiles <= 768)
+        hipLaunchKernelGGL(k_trtri_level<2>, dim3(tiles * 4), dim3(256), 0, st, L, T, U, ld, nt, s, step);
+    else
+        hipLaunchKernelGGL(k_trtri_level<4>, dim3(tiles), dim3(256), 0, st, L, T, U, ld, nt, s, step);
 }
 
 void launch_lauum(const double* U, double* Kinv, int ld, int nt, hipStream_t s)
