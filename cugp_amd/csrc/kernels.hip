@@ -272,16 +272,21 @@ __global__ __launch_bounds__(256, 2) void k_syrk_trail(double* __restrict__ A, i
 }
 
 // ---- K^-1 (lower tiles, diagonal tiles complete) = U * U^T, U = L^-T upper ----
+template <int WM>
 __global__ __launch_bounds__(256, 2) void k_lauum(const double* __restrict__ U, double* __restrict__ Kinv, int ld,
                                                   int nt)
 {
-    __shared__ __attribute__((aligned(16))) char smem[GEMM_LDS];
+    __shared__ __attribute__((aligned(16))) char smem[Geo<WM>::LDS];
+    constexpr int SUB = 4 / WM, BT = 32 * WM;
     int ti, tj;
-    tri_index(blockIdx.x, ti, tj);       // ascending ti = longest k ranges first
-    d4 acc[4][4];
+    tri_index(blockIdx.x / (SUB * SUB), ti, tj);       // ascending ti = longest k ranges first
+    const int sub = blockIdx.x % (SUB * SUB);
+    const int si = (sub / SUB) * BT, sj = (sub % SUB) * BT;
+    d4 acc[WM][WM];
     acc_zero(acc);
-    tile_nt<false>(U + (size_t)ti * TILE * ld, ld, U + (size_t)tj * TILE * ld, ld, ti * TILE, nt * TILE, acc, smem);
-    tile_store(Kinv + (size_t)ti * TILE * ld + tj * TILE, ld, acc, 1.0);
+    tile_nt<false>(U + (size_t)(ti * TILE + si) * ld, ld, U + (size_t)(tj * TILE + sj) * ld, ld, ti * TILE,
+                   nt * TILE, acc, smem);
+    tile_store(Kinv + (size_t)(ti * TILE + si) * ld + tj * TILE + sj, ld, acc, 1.0);
 }
 
 // ---- recursive-doubling inverse, one level.  Blocks of s tiles: [A 0; C B]^-1 = [TA 0; -TB C TA, TB].
@@ -901,8 +906,11 @@ __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, in
                    d64 + (size_t)kn * 8192, logdet_part + kn, sm, red);
         return;
     }
+    // tile 0 = (kb+1,kb+1) is the diagonal one above.  Odd steps walk the tiles backwards so the tiles
+    // written last by step kb (still in the 256 MiB Infinity Cache) are the first read by step kb+1.
     int ti, tj;
-    tri_index(blockIdx.x - NDIAGWG + 1, ti, tj);      // tile 0 = (kb+1,kb+1) is the diagonal one above
+    const int tlin = blockIdx.x - NDIAGWG + 1;
+    tri_index((kb & 1) ? (int)gridDim.x - NDIAGWG + 1 - tlin : tlin, ti, tj);
     const int k0 = kb * TILE;
     const int i0 = (kb + 1 + ti) * TILE, j0 = (kb + 1 + tj) * TILE;
     d4 acc[4][4];
@@ -1300,7 +1308,10 @@ void launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, i
 
 void launch_lauum(const double* U, double* Kinv, int ld, int nt, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_lauum, dim3(tri_count(nt)), dim3(256), 0, s, U, Kinv, ld, nt);
+    if (tri_count(nt) <= 768)
+        hipLaunchKernelGGL(k_lauum<2>, dim3(tri_count(nt) * 4), dim3(256), 0, s, U, Kinv, ld, nt);
+    else
+        hipLaunchKernelGGL(k_lauum<4>, dim3(tri_count(nt)), dim3(256), 0, s, U, Kinv, ld, nt);
 }
 
 void launch_predict_gemm(const double* Ks, const double* T, double* W, int ld, int ntt, int nt, hipStream_t s)
