@@ -65,10 +65,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=N_METRIC, help="rows per expert (metric config: 8192)")
-    ap.add_argument("--d", type=int, default=D_METRIC)
+    ap.add_argument("--rows", dest="n", type=int, default=N_METRIC, help="rows per expert (metric config: 8192)")
+    ap.add_argument("--dims", dest="d", type=int, default=D_METRIC)
     ap.add_argument("--experts-per-gpu", type=int, default=1)
     ap.add_argument("--cpu-sample", type=int, default=2048, help="rows for the CPU baseline (0 = skip)")
+    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only to rehearse "
+                    "the multi-rank path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     args = ap.parse_args()
 
     import torch
@@ -83,11 +86,16 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     from cugp_amd.bcm import ShardedBCM
 
@@ -120,7 +128,7 @@ def main():
         ll, g, _ = step(args.warmup + i)
     fence()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
@@ -148,7 +156,7 @@ def main():
         if ks["launches"] > 0:
             ach = ks["flop"] / (ks["sum_ms"] * 1e-3) / 1e12
             out["roofline"] = {
-                "kernel": "k_syrk_trail (Cholesky trailing update, fp64 MFMA 16x16x4)",
+                "kernel": "k_syrk_step (Cholesky trailing update, fp64 MFMA 16x16x4, K=128 per launch)",
                 "bound": "mfma", "achieved": ach, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": ach / MFMA_F64_PEAK_TFLOPS, "traffic": None,
                 "launches": int(ks["launches"]), "avg_launch_us": 1e3 * ks["sum_ms"] / ks["launches"],

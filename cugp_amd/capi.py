@@ -79,6 +79,7 @@ SIGNATURES = {
     "cugp_bcm_cg_solve": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, _ip]),
     "cugp_test_gemm_nt": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int]),
     "cugp_mfma_peak_tflops": (C.c_int, [C.c_int, _dp]),
+    "cugp_set_tuning": (C.c_int, [C.c_int, C.c_int]),
 }
 
 _lib = None

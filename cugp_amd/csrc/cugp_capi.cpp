@@ -755,6 +755,13 @@ int cugp_rprop_solve(cugp_gp* g, int iters, double* trace, int trace_cap, int* n
 }
 
 // ---------------------------------------------------------------- test hooks
+int cugp_set_tuning(int key, int value)
+{
+    if (key < 0 || key >= TUNE_COUNT) return CUGP_ERR_INVALID;
+    g_tune[key] = value;
+    return CUGP_OK;
+}
+
 int cugp_test_gemm_nt(int m, int n, int k, const double* A, const double* B, double* C, int device)
 {
     if (m <= 0 || n <= 0 || k <= 0 || m % TILE || n % TILE || k % 16 || !A || !B || !C)

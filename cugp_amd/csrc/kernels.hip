@@ -24,6 +24,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 namespace cugp {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -160,7 +162,8 @@ __device__ __forceinline__ void acc_zero(d4 (&acc)[WM][WM])
 #define ACC_COL2(np) (wc * 16 * WM + (np) * 32 + 2 * (lane & 15))
 
 // acc = C   (the K loop then accumulates straight onto it: no read-modify-write epilogue)
-template <int WM>
+// STREAM: the tile is touched once per launch -> non-temporal accesses keep the shared operand panels in L2
+template <bool STREAM = false, int WM>
 __device__ __forceinline__ void tile_load(const double* __restrict__ C, int ldc, d4 (&acc)[WM][WM])
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -171,14 +174,15 @@ __device__ __forceinline__ void tile_load(const double* __restrict__ C, int ldc,
         for (int r = 0; r < 4; r++)
 #pragma unroll
             for (int np = 0; np < WM / 2; np++) {
-                const d2 v = *(const d2*)(C + (size_t)ACC_ROW(m, r) * ldc + ACC_COL2(np));
+                const d2* src = (const d2*)(C + (size_t)ACC_ROW(m, r) * ldc + ACC_COL2(np));
+                const d2 v = STREAM ? __builtin_nontemporal_load(src) : *src;
                 acc[m][2 * np][r] = v[0];
                 acc[m][2 * np + 1][r] = v[1];
             }
 }
 
 // C = alpha * acc
-template <int WM>
+template <bool STREAM = false, int WM>
 __device__ __forceinline__ void tile_store(double* __restrict__ C, int ldc, const d4 (&acc)[WM][WM], double alpha)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -189,8 +193,12 @@ __device__ __forceinline__ void tile_store(double* __restrict__ C, int ldc, cons
         for (int r = 0; r < 4; r++)
 #pragma unroll
             for (int np = 0; np < WM / 2; np++)
-                *(d2*)(C + (size_t)ACC_ROW(m, r) * ldc + ACC_COL2(np)) =
-                    (d2){alpha * acc[m][2 * np][r], alpha * acc[m][2 * np + 1][r]};
+            {
+                d2* dst = (d2*)(C + (size_t)ACC_ROW(m, r) * ldc + ACC_COL2(np));
+                const d2 v = (d2){alpha * acc[m][2 * np][r], alpha * acc[m][2 * np + 1][r]};
+                if (STREAM) __builtin_nontemporal_store(v, dst);
+                else *dst = v;
+            }
 }
 
 // Ct[col][row] = alpha*acc  (transposed store).  The tile is turned through LDS (free after the K loop)
@@ -879,7 +887,7 @@ constexpr int STEP_LDS = POTF2_LDS;                   // >= GEMM_LDS; two such w
 __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, int ld, int kb,
                                                       double* __restrict__ d16, double* __restrict__ d64,
                                                       double* __restrict__ logdet_part,
-                                                      unsigned* __restrict__ tickets)
+                                                      unsigned* __restrict__ tickets, int nfull)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ double red[TILE];
@@ -908,15 +916,33 @@ __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, in
     }
     // tile 0 = (kb+1,kb+1) is the diagonal one above.  Odd steps walk the tiles backwards so the tiles
     // written last by step kb (still in the 256 MiB Infinity Cache) are the first read by step kb+1.
-    int ti, tj;
-    const int tlin = blockIdx.x - NDIAGWG + 1;
-    tri_index((kb & 1) ? (int)gridDim.x - NDIAGWG + 1 - tlin : tlin, ti, tj);
+    // Regular tiles: `nfull` of them as 128x128 workgroups; the rest (a partial last round that would
+    // leave most of the chip idle for a whole tile time) as four 64x64 workgroups each.
     const int k0 = kb * TILE;
-    const int i0 = (kb + 1 + ti) * TILE, j0 = (kb + 1 + tj) * TILE;
-    d4 acc[4][4];
-    tile_load(A + (size_t)i0 * ld + j0, ld, acc);
-    tile_nt<true>(A + (size_t)i0 * ld + k0, ld, A + (size_t)j0 * ld + k0, ld, 0, TILE, acc, (char*)sm);
-    tile_store(A + (size_t)i0 * ld + j0, ld, acc, 1.0);
+    const int x = blockIdx.x - NDIAGWG;
+    if (x < nfull) {
+        // Workgroups are dealt round-robin over the 8 XCDs (private L2 each): give every XCD one contiguous
+        // run of the tile list, so neighbouring tiles (same panel rows) share an L2 (bijective for any count).
+        // Odd steps walk backwards: the tiles written last by step kb are the first read by step kb+1.
+        int ti, tj;
+        const int xg = x & 7, xq = nfull >> 3, xr = nfull & 7;
+        const int tlin = (xg < xr ? xg * (xq + 1) : xr * (xq + 1) + (xg - xr) * xq) + (x >> 3) + 1;
+        tri_index((kb & 1) ? nfull + 1 - tlin : tlin, ti, tj);       // tile 0 = (kb+1,kb+1) is the diagonal one
+        const int i0 = (kb + 1 + ti) * TILE, j0 = (kb + 1 + tj) * TILE;
+        d4 acc[4][4];
+        tile_load<true>(A + (size_t)i0 * ld + j0, ld, acc);
+        tile_nt<true>(A + (size_t)i0 * ld + k0, ld, A + (size_t)j0 * ld + k0, ld, 0, TILE, acc, (char*)sm);
+        tile_store<true>(A + (size_t)i0 * ld + j0, ld, acc, 1.0);
+    } else {
+        int ti, tj;
+        const int y = x - nfull;
+        tri_index(nfull + 1 + (y >> 2), ti, tj);
+        const int i0 = (kb + 1 + ti) * TILE + ((y >> 1) & 1) * 64, j0 = (kb + 1 + tj) * TILE + (y & 1) * 64;
+        d4 acc[2][2];
+        tile_load<true>(A + (size_t)i0 * ld + j0, ld, acc);
+        tile_nt<true>(A + (size_t)i0 * ld + k0, ld, A + (size_t)j0 * ld + k0, ld, 0, TILE, acc, (char*)sm);
+        tile_store<true>(A + (size_t)i0 * ld + j0, ld, acc, 1.0);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1202,6 +1228,8 @@ __global__ __launch_bounds__(256) void k_predict_finish(const double* __restrict
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
+int g_tune[TUNE_COUNT] = {768, 1200, 384};   // defaults chosen by interleaved A/B runs (tools/ab.py)
+
 static inline int tri_count(int n) { return n * (n + 1) / 2; }
 
 void launch_kbuild(const double* X, int n, int d, int npad, HyperScalars h, double* K, bool full, hipStream_t s)
@@ -1280,8 +1308,13 @@ void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* d6
     const int m = nt - kb - 1;
     if (m <= 0) return;
     set_big_lds();
-    hipLaunchKernelGGL(k_syrk_step, dim3(NDIAGWG + tri_count(m) - 1), dim3(256), STEP_LDS, s, A, ld, kb, d16, d64,
-                       logdet_part, tickets);
+    // tiles beyond the last full round of 512 workgroup slots run as 64x64 quarters when that round
+    // would be less than three quarters full
+    const int ntl = tri_count(m) - 1;
+    int nfull = ntl;
+    if (ntl >= 512 && (ntl % 512) <= g_tune[TUNE_SYRK_REM_MAX]) nfull = ntl - ntl % 512;
+    hipLaunchKernelGGL(k_syrk_step, dim3(NDIAGWG + nfull + 4 * (ntl - nfull)), dim3(256), STEP_LDS, s, A, ld, kb, d16,
+                       d64, logdet_part, tickets, nfull);
 }
 
 void launch_syrk_diag(double* A, int ld, int kb, hipStream_t s)
@@ -1300,7 +1333,7 @@ void launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, i
     }
     if (tiles <= 0) return;
     // few 128-tiles cannot fill 512 workgroup slots: use 64x64 output tiles (4x the parallelism) there
-    if (tiles <= 768)
+    if (tiles <= g_tune[TUNE_TRTRI_WM2_MAX])
         hipLaunchKernelGGL(k_trtri_level<2>, dim3(tiles * 4), dim3(256), 0, st, L, T, U, ld, nt, s, step);
     else
         hipLaunchKernelGGL(k_trtri_level<4>, dim3(tiles), dim3(256), 0, st, L, T, U, ld, nt, s, step);
@@ -1308,7 +1341,7 @@ void launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, i
 
 void launch_lauum(const double* U, double* Kinv, int ld, int nt, hipStream_t s)
 {
-    if (tri_count(nt) <= 768)
+    if (tri_count(nt) <= g_tune[TUNE_LAUUM_WM2_MAX])
         hipLaunchKernelGGL(k_lauum<2>, dim3(tri_count(nt) * 4), dim3(256), 0, s, U, Kinv, ld, nt);
     else
         hipLaunchKernelGGL(k_lauum<4>, dim3(tri_count(nt)), dim3(256), 0, s, U, Kinv, ld, nt);

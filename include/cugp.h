@@ -150,6 +150,7 @@ int cugp_bcm_cg_solve(cugp_bcm *b, int budget, double *trace, int trace_cap, int
 /* ---- test / bench hooks ---- */
 int cugp_test_gemm_nt(int m, int n, int k, const double *A, const double *B, double *C, int device);
 int cugp_mfma_peak_tflops(int device, double *tflops);
+int cugp_set_tuning(int key, int value);     /* launch-shape thresholds (kernels.h TUNE_*), for A/B runs */
 
 #ifdef __cplusplus
 }
