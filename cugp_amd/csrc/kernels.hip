@@ -578,18 +578,23 @@ __device__ __forceinline__ double rsqrt_nr(double x)
 }
 
 // Cholesky of one 16x16 micro tile held in LDS (rows padded to 17), by ONE wave: lane l owns row
-// l & 15 in registers, right-looking, pivots and column factors broadcast with v_readlane.
-// The pivot chain is the latency floor of the whole factorisation, so it is kept short: the second
-// Newton step of 1/sqrt(pivot) is folded into the column scaling, and the next pivot is formed
-// first (each lane with its own factor: lane c+1 holds the right value) before the general update.
-// Writes the factor back (upper zeroed) and 1/L_cc into rinv[0..15].
-__device__ __forceinline__ void micro_factor(double* __restrict__ tile, double* __restrict__ rinv)
+// l & 15 in registers, right-looking.  The pivot chain is the latency floor of the whole
+// factorisation, so it is kept short and cheap to issue:
+//   * the next pivot is formed lane-locally (lane c+1 holds the right value) and broadcast with one
+//     v_readlane pair, so its 1/sqrt chain starts at once;
+//   * the second Newton step of 1/sqrt(pivot) is folded into the column scaling;
+//   * the column factors needed by the other 14 columns go through a 128-byte LDS buffer and come
+//     back as uniform 16-byte reads (one instruction per two columns instead of four v_readlane).
+// Writes the factor back (upper zeroed) and 1/L_cc into rinv[0..15].  colbuf: 32 doubles of LDS.
+__device__ __forceinline__ void micro_factor(double* __restrict__ tile, double* __restrict__ rinv,
+                                             double* __restrict__ colbuf)
 {
     const int lane = threadIdx.x & 63, i = lane & 15;
     double r[MT];
 #pragma unroll
     for (int c = 0; c < MT; c++) r[c] = tile[i * (MT + 1) + c];
     double piv = readlane_f64(r[0], 0);
+    double myrinv = 0.0;
 #pragma unroll
     for (int c = 0; c < MT; c++) {
         // y1 = rsq + one Newton step (2^-48); second step folded: l = a*y1 + (a*h1)*e1  (2^-52.7 measured)
@@ -604,14 +609,21 @@ __device__ __forceinline__ void micro_factor(double* __restrict__ tile, double* 
             const double dn = __builtin_fma(-lc, lc, r[c + 1]);      // lane c+1: next pivot
             piv = readlane_f64(dn, c + 1);
         }
-        if (lane == c) rinv[c] = __builtin_fma(h1, e1, y);
+        myrinv = (i == c) ? __builtin_fma(h1, e1, y) : myrinv;
+        if (c + 1 < MT) {
+            double* cb = colbuf + (c & 1) * MT;
+            cb[i] = lc;                                               // lanes 16..63 mirror the same values
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int c2 = c + 1; c2 < MT; c2++) {
-            const double o = readlane_f64(lc, c2);
-            r[c2] = __builtin_fma(-lc, o, r[c2]);
+            for (int c2 = (c + 1) & ~1; c2 < MT; c2 += 2) {
+                const d2 o = *(const d2*)(cb + c2);
+                if (c2 > c) r[c2] = __builtin_fma(-lc, o[0], r[c2]);
+                r[c2 + 1] = __builtin_fma(-lc, o[1], r[c2 + 1]);
+            }
         }
     }
     if (lane < MT) {
+        rinv[i] = myrinv;
 #pragma unroll
         for (int c = 0; c < MT; c++) tile[i * (MT + 1) + c] = (c <= i) ? r[c] : 0.0;
     }
@@ -680,6 +692,19 @@ __device__ unsigned long long g_stamps[64];
 #define STAMP(i)
 #endif
 
+// inverse of diagonal micro tile q into d16 and its log-det share sum_i log L_ii = -sum_i log(1/L_ii)
+// into red[q] (one wave; lanes 16..63 contribute zero; fixed shuffle order -> reproducible)
+__device__ __forceinline__ void micro_inverse_logdet(const double* __restrict__ sm, const double* __restrict__ rinv,
+                                                     double* __restrict__ d16blk, double* __restrict__ red, int q)
+{
+    const int lane = threadIdx.x & 63;
+    micro_inverse(sm + mt_off(q, q), rinv + q * MT, d16blk + (size_t)q * (MT * MT));
+    double v = (lane < MT) ? -log(rinv[q * MT + lane]) : 0.0;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    if (lane == 0) red[q] = v;
+}
+
 // one MFMA 16x16x16 product on LDS micro tiles, "NN": acc += A(tile a)[row][k] * B(tile b)[k][col]
 __device__ __forceinline__ d4 micro_mma_nn(const double* __restrict__ a, const double* __restrict__ b, d4 acc)
 {
@@ -714,6 +739,7 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ Ab, int ld, doub
                                            double* __restrict__ sm, double* __restrict__ red)
 {
     double* rinv = sm + NLT * MTS;                          // 1 / L_ii, 128 entries
+    double* colbuf = red + 64;                              // red[0..7]: log-det shares; red[64..95]: pivot columns
     const int t = threadIdx.x, wave = t >> 6;
     __builtin_amdgcn_s_setprio(3);                          // this workgroup is the critical path of the step
 
@@ -726,7 +752,7 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ Ab, int ld, doub
     }
     __syncthreads();
     STAMP(1);
-    if (wave == 0) micro_factor(sm + mt_off(0, 0), rinv);
+    if (wave == 0) micro_factor(sm + mt_off(0, 0), rinv, colbuf);
     __syncthreads();
     STAMP(2);
 
@@ -755,7 +781,7 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ Ab, int ld, doub
             micro_update(sm, jb + 1, jb + 1, jb);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             STAMP(4 + 3 * jb);
-            micro_factor(sm + mt_off(jb + 1, jb + 1), rinv + (jb + 1) * MT);
+            micro_factor(sm + mt_off(jb + 1, jb + 1), rinv + (jb + 1) * MT, colbuf);
             STAMP(5 + 3 * jb);
         } else {
             int n = 0;                                      // column jb+1 first, then the rest
@@ -764,16 +790,21 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ Ab, int ld, doub
             for (int bj = jb + 2; bj < NMT; bj++)
                 for (int bi = bj; bi < NMT; bi++, n++)
                     if (n % 3 == wave - 1) micro_update(sm, bi, bj, jb);
-            // the inverse of the diagonal micro tile just finished, by a wave that has slack
-            if (wave == 1 + (jb % 3))
-                micro_inverse(sm + mt_off(jb, jb), rinv + jb * MT, d16blk + (size_t)jb * (MT * MT));
+            // inverses of finished diagonal micro tiles (+ their log-det share), only from step 3 on, when
+            // waves 1..3 have slack: pending tiles 0..3 at jb = 3 (one wave takes two), then one per step
+            if (jb >= 3) {
+                int q = -1, q2 = -1;
+                if (jb == 3) { q = wave - 1; if (wave == 3) q2 = 3; }
+                else if (wave == 1 + (jb % 3)) q = jb;
+                if (q >= 0) micro_inverse_logdet(sm, rinv, d16blk, red, q);
+                if (q2 >= 0) micro_inverse_logdet(sm, rinv, d16blk, red, q2);
+            }
         }
         __syncthreads();
     }
 
     STAMP(30);
-    if (wave == 1)
-        micro_inverse(sm + mt_off(NMT - 1, NMT - 1), rinv + (NMT - 1) * MT, d16blk + (size_t)(NMT - 1) * (MT * MT));
+    if (wave == 1) micro_inverse_logdet(sm, rinv, d16blk, red, NMT - 1);
     {   // factor back to global (lower micro tiles; diagonal tiles carry zeros above the diagonal)
         const int r = t >> 4, c = t & 15;
         for (int bi = 0; bi < NMT; bi++)
@@ -781,14 +812,13 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ Ab, int ld, doub
                 Ab[(size_t)(bi * MT + r) * ld + bj * MT + c] = sm[mt_off(bi, bj) + r * (MT + 1) + c];
     }
     STAMP(31);
-    // log-determinant share of this block, summed in a fixed order: log L_ii = -log(1/L_ii)
-    if (t < TILE) red[t] = -log(rinv[t]);
     __syncthreads();
-    for (int w = TILE / 2; w > 0; w >>= 1) {
-        if (t < w) red[t] += red[t + w];
-        __syncthreads();
+    // log-determinant share of this block: the 8 micro-tile shares summed in a fixed order
+    if (t == 0) {
+        double acc = 0.0;
+        for (int jb = 0; jb < NMT; jb++) acc += red[jb];
+        *logdet_out = acc;
     }
-    if (t == 0) *logdet_out = red[0];
     STAMP(32);
 
     // ---- inverses of the two 64x64 diagonal sub-blocks, in place over the factor (already stored) ----
