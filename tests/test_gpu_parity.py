@@ -300,3 +300,27 @@ def test_full_size_properties(gp_mod):
         lm = g.compute_loglikelihood()
         fd = -(lp - lm) / (2 * h)                       # gradient is of -LL
         assert abs(fd - gr[j]) <= 1e-5 * max(1.0, abs(gr[j])), (j, fd, gr[j])
+
+
+# ------------------------------------------------------------------ chunk-file driver (config 4/5 shape)
+def test_train_driver_on_chunk_files(tmp_path, oracle):
+    """cugp_amd.train on 4 chunk files (single rank): same end point as the oracle's BCM cg_solve."""
+    import subprocess, sys, re, os
+    from cugp_amd import dataset
+    X, y = synth(4 * 60, d=3, seed=11, scale=3.0)
+    parts = dataset.shard(X, y, 4)
+    for i, (xs, ys) in enumerate(parts):
+        dataset.write_chunk(str(tmp_path / ("in%d.txt" % i)), str(tmp_path / ("lab%d.txt" % i)), xs, ys)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "cugp_amd.train", "--numchunks", "4", "--rows", "60",
+                          "--inputs", str(tmp_path / "in"), "--labels", str(tmp_path / "lab"), "--hp", "0.5", "0.5",
+                          "0.5", "--budget", "40"], capture_output=True, text=True, cwd=root, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    hp = [float(v) for v in re.search(r"PLEASE-SEE 3 : ([-\d.]+), ([-\d.]+), ([-\d.]+)", out.stdout).groups()]
+    Xr = np.vstack([dataset.load_chunk(str(tmp_path / ("in%d.txt" % i)), str(tmp_path / ("lab%d.txt" % i)))[0]
+                    for i in range(4)])
+    yr = np.concatenate([dataset.load_chunk(str(tmp_path / ("in%d.txt" % i)), str(tmp_path / ("lab%d.txt" % i)))[1]
+                         for i in range(4)])
+    b = oracle.bcm(Xr, yr, 4, [0.5, 0.5, 0.5])
+    fin, _ = b.cg_solve(40)
+    assert np.allclose(hp, fin, atol=5e-5), (hp, fin)
