@@ -662,6 +662,11 @@ void oracle_bcm_set_loghyper(oracle_bcm *b, const double hp[3])
     for (int k = 0; k < b->K; k++) oracle_gp_set_loghyper(b->experts[k], b->hp);
 }
 
+void oracle_bcm_get_loghyper(const oracle_bcm *b, double hp[3])
+{
+    for (int i = 0; i < 3; i++) hp[i] = b->hp[i];
+}
+
 /* BCM.cpp:182-198: plain sum over experts in index order */
 double oracle_bcm_loglik(oracle_bcm *b, double *per_expert)
 {

@@ -66,6 +66,7 @@ oracle_bcm *oracle_bcm_create(const double *X, const double *y, int N, int D, in
 void oracle_bcm_destroy(oracle_bcm *b);
 int oracle_bcm_expert_rows(const oracle_bcm *b, int k, int *offset);
 void oracle_bcm_set_loghyper(oracle_bcm *b, const double hp[3]);                      /* BCM.cpp:123-130 */
+void oracle_bcm_get_loghyper(const oracle_bcm *b, double hp[3]);
 double oracle_bcm_loglik(oracle_bcm *b, double *per_expert /* K or NULL */);          /* BCM.cpp:182-198 */
 void oracle_bcm_grad(oracle_bcm *b, double g[3]);                                     /* BCM.cpp:153-180 */
 void oracle_bcm_predict(oracle_bcm *b, const double *Xt, int nt, double *mean, double *var); /* :64-83 */

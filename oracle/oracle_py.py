@@ -77,6 +77,7 @@ class Oracle:
         L.oracle_bcm_expert_rows.restype = C.c_int
         L.oracle_bcm_expert_rows.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
         L.oracle_bcm_set_loghyper.argtypes = [C.c_void_p, _dp]
+        L.oracle_bcm_get_loghyper.argtypes = [C.c_void_p, _dp]
         L.oracle_bcm_loglik.restype = C.c_double
         L.oracle_bcm_loglik.argtypes = [C.c_void_p, _dp]
         L.oracle_bcm_grad.argtypes = [C.c_void_p, _dp]
@@ -254,7 +255,9 @@ class OracleBCM:
     def cg_solve(self, budget=100):
         tr = np.zeros((4 * budget + 8, 4))
         ne = self.o.lib.oracle_bcm_cg_solve(self.h, budget, _p(tr), tr.shape[0])
-        return tr[ne - 1, :3].copy() if ne else None, tr[:ne]
+        final = np.empty(3)
+        self.o.lib.oracle_bcm_get_loghyper(self.h, _p(final))     # the kept (best) point, not the last probe
+        return final, tr[:ne]
 
     def close(self):
         if self.h:
