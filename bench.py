@@ -153,12 +153,19 @@ def main():
             "phase_ms_last": {k: round(v, 4) for k, v in ph.items()},
             "ll_last": ll, "grad_last": [float(v) for v in g],
         }
+        traffic = None      # HBM bytes per launch from the PMC passes committed under profiles/ (tools/pmc.sh,
+        try:                # tools/pmc_summary.py: 2 x FETCH_SIZE + WRITE_SIZE, per launch); not collectable in-process
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
+                if args.n == N_METRIC:
+                    traffic = json.load(f)["kernels"]["k_syrk_step"]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         if ks["launches"] > 0:
             ach = ks["flop"] / (ks["sum_ms"] * 1e-3) / 1e12
             out["roofline"] = {
                 "kernel": "k_syrk_step (Cholesky trailing update, fp64 MFMA 16x16x4, K=128 per launch)",
                 "bound": "mfma", "achieved": ach, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / MFMA_F64_PEAK_TFLOPS, "traffic": None,
+                "frac": ach / MFMA_F64_PEAK_TFLOPS, "traffic": traffic,
                 "launches": int(ks["launches"]), "avg_launch_us": 1e3 * ks["sum_ms"] / ks["launches"],
                 "algorithmic_flop_per_launch": ks["flop"] / ks["launches"],
             }

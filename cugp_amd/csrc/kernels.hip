@@ -578,13 +578,14 @@ __device__ __forceinline__ double rsqrt_nr(double x)
 }
 
 // Cholesky of one 16x16 micro tile held in LDS (rows padded to 17), by ONE wave: lane l owns row
-// l & 15 in registers, right-looking.  The pivot chain is the latency floor of the whole
-// factorisation, so it is kept short and cheap to issue:
-//   * the next pivot is formed lane-locally (lane c+1 holds the right value) and broadcast with one
-//     v_readlane pair, so its 1/sqrt chain starts at once;
-//   * the second Newton step of 1/sqrt(pivot) is folded into the column scaling;
-//   * the column factors needed by the other 14 columns go through a 128-byte LDS buffer and come
-//     back as uniform 16-byte reads (one instruction per two columns instead of four v_readlane).
+// l & 15 in registers, right-looking.  A wave issues one fp64 VALU instruction per ~6.5 cycles, so the
+// pivot loop (the latency floor of the whole factorisation) is written for few instructions and no stalls:
+//   * 1/sqrt(pivot): v_rsq_f64 seed (2^-24) + ONE third-order step y0 (1 + e/2 + 3e^2/8), e = 1 - x y0^2,
+//     folded into the column scaling (error 5/16 e^3 ~ 3e-24: below rounding);
+//   * column c+1 is updated at once with a v_readlane broadcast and gives the next pivot, so the next
+//     1/sqrt chain starts immediately;
+//   * the factors for columns >= c+2 go through a 128-byte LDS buffer and come back as uniform 16-byte
+//     reads; they are applied ONE PIVOT LATER, so the LDS round trip never stalls the chain.
 // Writes the factor back (upper zeroed) and 1/L_cc into rinv[0..15].  colbuf: 32 doubles of LDS.
 __device__ __forceinline__ void micro_factor(double* __restrict__ tile, double* __restrict__ rinv,
                                              double* __restrict__ colbuf)
@@ -595,30 +596,35 @@ __device__ __forceinline__ void micro_factor(double* __restrict__ tile, double* 
     for (int c = 0; c < MT; c++) r[c] = tile[i * (MT + 1) + c];
     double piv = readlane_f64(r[0], 0);
     double myrinv = 0.0;
+    double lprev = 0.0;                       // my factor of the previous pivot column
+    d2 oprev[MT / 2];                         // the previous pivot column, as read back from LDS
 #pragma unroll
     for (int c = 0; c < MT; c++) {
-        // y1 = rsq + one Newton step (2^-48); second step folded: l = a*y1 + (a*h1)*e1  (2^-52.7 measured)
-        double y = __builtin_amdgcn_rsq(piv);
-        const double e0 = __builtin_fma(-piv * y, y, 1.0);
-        y = __builtin_fma(0.5 * y, e0, y);
-        const double e1 = __builtin_fma(-piv * y, y, 1.0);
-        const double h1 = 0.5 * y;
-        const double lc = __builtin_fma(r[c] * h1, e1, r[c] * y);
-        r[c] = lc;
-        if (c + 1 < MT) {
-            const double dn = __builtin_fma(-lc, lc, r[c + 1]);      // lane c+1: next pivot
-            piv = readlane_f64(dn, c + 1);
-        }
-        myrinv = (i == c) ? __builtin_fma(h1, e1, y) : myrinv;
-        if (c + 1 < MT) {
-            double* cb = colbuf + (c & 1) * MT;
-            cb[i] = lc;                                               // lanes 16..63 mirror the same values
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const double y0 = __builtin_amdgcn_rsq(piv);
+        const double e = __builtin_fma(-piv * y0, y0, 1.0);
+        const double q = e * __builtin_fma(e, 0.375, 0.5);
+        // deferred: previous pivot's column applied to columns >= c+1 (column c got it right away)
+        if (c >= 1) {
 #pragma unroll
             for (int c2 = (c + 1) & ~1; c2 < MT; c2 += 2) {
-                const d2 o = *(const d2*)(cb + c2);
-                if (c2 > c) r[c2] = __builtin_fma(-lc, o[0], r[c2]);
-                r[c2 + 1] = __builtin_fma(-lc, o[1], r[c2 + 1]);
+                if (c2 > c) r[c2] = __builtin_fma(-lprev, oprev[c2 / 2][0], r[c2]);
+                r[c2 + 1] = __builtin_fma(-lprev, oprev[c2 / 2][1], r[c2 + 1]);
+            }
+        }
+        const double ry = r[c] * y0;
+        const double lc = __builtin_fma(ry, q, ry);
+        r[c] = lc;
+        myrinv = (i == c) ? __builtin_fma(y0, q, y0) : myrinv;
+        if (c + 1 < MT) {
+            const double o1 = readlane_f64(lc, c + 1);
+            r[c + 1] = __builtin_fma(-lc, o1, r[c + 1]);              // column c+1, every row
+            piv = readlane_f64(r[c + 1], c + 1);                      // next pivot
+            if (c + 2 < MT) {
+                double* cb = colbuf + (c & 1) * MT;
+                cb[i] = lc;                                           // lanes 16..63 mirror the same values
+#pragma unroll
+                for (int c2 = (c + 2) & ~1; c2 < MT; c2 += 2) oprev[c2 / 2] = *(const d2*)(cb + c2);
+                lprev = lc;
             }
         }
     }
@@ -791,14 +797,12 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ Ab, int ld, doub
                 for (int bi = bj; bi < NMT; bi++, n++)
                     if (n % 3 == wave - 1) micro_update(sm, bi, bj, jb);
             // inverses of finished diagonal micro tiles (+ their log-det share), only from step 3 on, when
-            // waves 1..3 have slack: pending tiles 0..3 at jb = 3 (one wave takes two), then one per step
-            if (jb >= 3) {
-                int q = -1, q2 = -1;
-                if (jb == 3) { q = wave - 1; if (wave == 3) q2 = 3; }
-                else if (wave == 1 + (jb % 3)) q = jb;
-                if (q >= 0) micro_inverse_logdet(sm, rinv, d16blk, red, q);
-                if (q2 >= 0) micro_inverse_logdet(sm, rinv, d16blk, red, q2);
-            }
+            // waves 1..3 have slack: tiles 0,1,2 at jb = 3; 3,4 at jb = 4; then one per step
+            int q = -1;
+            if (jb == 3) q = wave - 1;
+            else if (jb == 4) q = (wave <= 2) ? 2 + wave : -1;
+            else if (jb > 4 && wave == 1 + (jb % 3)) q = jb;
+            if (q >= 0) micro_inverse_logdet(sm, rinv, d16blk, red, q);
         }
         __syncthreads();
     }

@@ -1,0 +1,58 @@
+"""Summarise rocprofv3 PMC passes (tools/pmc.sh) into profiles/r01_pmc_summary.json.
+FETCH_SIZE is doubled before use: on gfx950 it reports half the bytes of wide coalesced reads
+(MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact for 16-byte-per-lane stores.  Units: KiB."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out")
+KERNELS = ("k_syrk_step", "k_lauum", "k_trtri_level", "k_build", "k_trace", "k_potf2", "k_trsm_inv64")
+
+
+def load(tag):
+    f = glob.glob(os.path.join(src, "pmc_%s" % tag, "*", "*counter_collection.csv"))
+    return list(csv.DictReader(open(f[0]))) if f else []
+
+
+def short(name):
+    for k in KERNELS:
+        if k in name:
+            return k
+    return None
+
+
+out = {"note": __doc__.strip(), "kernels": {}}
+for tag, key in (("FETCH_SIZE", "fetch_kib_raw"), ("WRITE_SIZE", "write_kib")):
+    agg, n = collections.defaultdict(float), collections.Counter()
+    for r in load(tag):
+        k = short(r["Kernel_Name"])
+        if k and r["Counter_Name"] == tag:
+            agg[k] += float(r["Counter_Value"])
+            n[k] += 1
+    for k in agg:
+        d = out["kernels"].setdefault(k, {})
+        d[key] = agg[k]
+        d["launches"] = n[k]
+sq = collections.defaultdict(lambda: collections.defaultdict(float))
+for r in load("SQ_WAVE_CYCLES"):
+    k = short(r["Kernel_Name"])
+    if k:
+        sq[k][r["Counter_Name"]] += float(r["Counter_Value"])
+for k, v in sq.items():
+    d = out["kernels"].setdefault(k, {})
+    wc = v.get("SQ_WAVE_CYCLES", 0.0)
+    d["sq"] = {n: x for n, x in v.items()}
+    if wc:
+        d["mfma_busy_per_wave_cycle"] = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / wc
+        d["wait_inst_any_frac"] = v.get("SQ_WAIT_INST_ANY", 0.0) / wc
+        d["lds_bank_conflict_frac"] = v.get("SQ_LDS_BANK_CONFLICT", 0.0) / wc
+for k, d in out["kernels"].items():
+    if "fetch_kib_raw" in d and "write_kib" in d and d.get("launches"):
+        d["hbm_bytes_per_launch"] = (2.0 * d["fetch_kib_raw"] + d["write_kib"]) * 1024.0 / d["launches"]
+json.dump(out, open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json"), "w"), indent=1)
+for k, d in out["kernels"].items():
+    print(k, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in d.items() if a != "sq"})
