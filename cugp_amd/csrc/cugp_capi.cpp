@@ -50,9 +50,7 @@ constexpr int MAX_KEV = 4096;   // per-launch event pairs kept between resets
 
 struct cugp_gp {
     int n = 0, d = 0, npad = 0, nt = 0, device = 0;
-    hipStream_t stream = nullptr;   // main stream: everything is ordered here ...
-    hipStream_t chain = nullptr;    // ... except the diagonal-block chain of the factorisation (high priority)
-    std::vector<hipEvent_t> ev_p, ev_r;   // P[k]: diagonal block k factored; R[k]: panel k solved (R[nt]: inputs ready)
+    hipStream_t stream = nullptr;   // all device work of the handle is ordered here
     double *dX = nullptr, *dy = nullptr, *dA = nullptr, *dT = nullptr, *dU = nullptr, *dKinv = nullptr;
     double *dz = nullptr, *dalpha = nullptr, *dw = nullptr, *d16 = nullptr, *dlogdet = nullptr, *dpart = nullptr, *d64 = nullptr;
     double* dout = nullptr;
@@ -265,17 +263,6 @@ int cugp_create(int n, int d, int device, cugp_gp** out)
     *out = nullptr;
     hipError_t e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) {
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        e = hipStreamCreateWithPriority(&g->chain, hipStreamNonBlocking, hi);
-    }
-    g->ev_p.assign(g->nt + 1, nullptr);
-    g->ev_r.assign(g->nt + 1, nullptr);
-    for (int i = 0; i <= g->nt && e == hipSuccess; i++) {
-        e = hipEventCreateWithFlags(&g->ev_p[i], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&g->ev_r[i], hipEventDisableTiming);
-    }
     if (e == hipSuccess) e = hipMalloc((void**)&g->dX, (size_t)n * d * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&g->dy, (size_t)g->npad * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&g->dz, (size_t)g->npad * sizeof(double));
@@ -303,7 +290,6 @@ int cugp_destroy(cugp_gp* g)
     if (!g) return CUGP_OK;
     (void)hipSetDevice(g->device);
     if (g->stream) (void)hipStreamSynchronize(g->stream);
-    if (g->chain) (void)hipStreamSynchronize(g->chain);
     double* bufs[] = {g->dX, g->dy, g->dA, g->dT, g->dU, g->dKinv, g->dz, g->dalpha, g->dw, g->d16, g->dlogdet,
                       g->dpart, g->dout, g->d64};
     for (double* p : bufs)
@@ -313,9 +299,6 @@ int cugp_destroy(cugp_gp* g)
     for (int i = 0; i <= NPHASE; i++)
         if (g->pev[i]) (void)hipEventDestroy(g->pev[i]);
     for (hipEvent_t e : g->kev) (void)hipEventDestroy(e);
-    for (hipEvent_t e : g->ev_p) if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : g->ev_r) if (e) (void)hipEventDestroy(e);
-    if (g->chain) (void)hipStreamDestroy(g->chain);
     if (g->stream) (void)hipStreamDestroy(g->stream);
     delete g;
     return CUGP_OK;
