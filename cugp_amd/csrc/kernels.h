@@ -11,7 +11,9 @@ constexpr int TILE = 128;          // tile edge of every fp64 MFMA product and o
 enum { TUNE_LAUUM_WM2_MAX = 0,   // K^-1 product: use 64x64 tiles when there are at most this many 128-tiles
        TUNE_TRTRI_WM2_MAX = 1,   // inverse level: same rule
        TUNE_SYRK_REM_MAX = 2,    // trailing update: split the last partial round into 64x64 quarters when it has at most this many tiles
-       TUNE_COUNT = 3 };
+       TUNE_KNOB = 3,            // bit 0: s_setprio(1) around MFMA blocks; bit 1: stagger odd workgroups
+       TUNE_COUNT = 4 };
+void apply_knob();
 extern int g_tune[TUNE_COUNT];
 
 struct HyperScalars {              // exp(2*theta) evaluated on the host, as the reference does (covkernel.cpp:65-67)
@@ -34,10 +36,6 @@ void launch_potf2(double* A, int ld, int kb, double* d16, double* d64, double* l
 void launch_trsm_inv64(double* A, const double* d64, int ld, int kb, int nt, hipStream_t s);     // 3-phase, 64x64 inverses
 void launch_trtri_diag(const double* A, int ld, int kb, int nblocks, const double* d16, double* T, double* U,
                        hipStream_t s);
-void launch_trsm_panel(double* A, const double* T, int ld, int kb, int nt, hipStream_t s);   // L21 = A21 T11^T (GEMM form)
-void launch_trsm_strips(double* A, const double* d16, int ld, int kb, int nt, hipStream_t s);   // block substitution
-void launch_syrk_trail(double* A, int ld, int kb, int nt, bool skip_next_diag, hipStream_t s);
-void launch_syrk_diag(double* A, int ld, int kb, hipStream_t s);
 // trailing update of step kb fused with the factorisation of diagonal block kb+1 (tickets[kb] must be 0)
 void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* d64, double* logdet_part,
                       unsigned* tickets, hipStream_t s);    // tile (kb+1,kb+1) only, fine grained

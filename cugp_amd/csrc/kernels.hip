@@ -38,10 +38,11 @@ constexpr int BK = 16;                       // k depth per LDS stage
 // geometry of a tile product whose waves hold WM x WM MFMA tiles each (block edge 32*WM: 128 or 64)
 template <int WM> struct Geo {
     static constexpr int BT = 32 * WM;               // block tile edge
-    static constexpr int PLANE = BT * 16;            // bytes per k-pair plane (BT rows x 2 doubles)
+    static constexpr int PLANE = BT * 16 + 16;       // bytes per k-pair plane (BT rows x 2 doubles) + 16 B pad:
+                                                     // 8 staging lanes (8 planes of one row) hit 8 different 16-B slots
     static constexpr int OPER = (BK / 2) * PLANE;    // bytes per operand per stage
     static constexpr int STAGE = 2 * OPER;           // A + B
-    static constexpr int LDS = 2 * STAGE;            // double buffered: 64 KiB (WM=4) / 32 KiB (WM=2)
+    static constexpr int LDS = 2 * STAGE;            // double buffered: 66048 B (WM=4, dynamic LDS) / 33280 B (WM=2)
 };
 constexpr int GEMM_LDS = Geo<4>::LDS;
 
@@ -51,9 +52,6 @@ constexpr int MTS = MT * (MT + 1);                 // doubles per LDS micro tile
 constexpr int NMT = TILE / MT;                     // 8 micro tiles per edge
 constexpr int NLT = NMT * (NMT + 1) / 2;           // 36 lower micro tiles
 constexpr int POTF2_LDS = (NLT * MTS + TILE) * 8;  // tiles + 1/L_ii  = 79360 B
-
-template <int WM>
-__device__ __forceinline__ int lds_slot(int row, int plane) { return ((row + plane) & (32 * WM - 1)) * 16; }
 
 // B-operand rows are stored permuted inside each wave's column range so that MFMA tiles n = 2p, 2p+1
 // of a wave produce ADJACENT output columns in one lane (16-byte global accesses in the epilogue)
@@ -65,9 +63,38 @@ __device__ __forceinline__ int bpos(int R)
     return (R - q) + (((q >> 5) * 2 + (q & 1)) * 16) + ((q & 31) >> 1);
 }
 
+// One K stage (16 deep) of MFMAs out of LDS buffer `cur`.  Measured on gfx950: every VALU instruction a wave
+// issues between fp64 MFMAs costs MFMA issue time (pure MFMA stream 74 TF/s, +1 VALU per MFMA 62, +4: 55),
+// so the loop body carries NO address arithmetic: fragment addresses are one per-lane base + immediates.
+__constant__ int c_knob;      // run-time A/B switch for kernel-internal variants (cugp_set_tuning key 3)
+
+template <int WM>
+__device__ __forceinline__ void tile_stage_mma(const char* __restrict__ cur, int abase, int bbase,
+                                               d4 (&acc)[WM][WM], int knob)
+{
+    typedef Geo<WM> G;
+    if (knob & 1) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; kk++) {
+        double a[WM], b[WM];
+#pragma unroll
+        for (int m = 0; m < WM; m++) {
+            a[m] = *(const double*)(cur + abase + kk * 2 * G::PLANE + m * 256);
+            b[m] = *(const double*)(cur + bbase + kk * 2 * G::PLANE + m * 256);
+        }
+#pragma unroll
+        for (int m = 0; m < WM; m++)
+#pragma unroll
+            for (int n = 0; n < WM; n++)
+                acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+    }
+    if (knob & 1) __builtin_amdgcn_s_setprio(0);
+}
+
 // acc[m][n] += (NEGA ? -1 : 1) * A(i0.., kbeg..kend) * B(j0.., kbeg..kend)^T ; Ag -> A[i0][0], Bg -> B[j0][0];
 // kbeg, kend multiples of BK.  All 256 threads must call (barriers inside).  WM (deduced from acc) is the
 // number of 16x16 MFMA tiles per wave per dimension: 4 -> 128x128 block, 2 -> 64x64 block.
+// LDS image per operand and stage: [k-pair plane (padded by 16 B)][row][2 doubles].
 template <bool NEGA, int WM>
 __device__ __forceinline__ void tile_nt(const double* __restrict__ Ag, int lda, const double* __restrict__ Bg,
                                         int ldb, int kbeg, int kend, d4 (&acc)[WM][WM], char* smem)
@@ -85,12 +112,20 @@ __device__ __forceinline__ void tile_nt(const double* __restrict__ Ag, int lda, 
     int wa[WM], wb[WM];                                   // LDS byte offsets of my staging chunks
 #pragma unroll
     for (int q = 0; q < WM; q++) {
-        wa[q] = skp * G::PLANE + lds_slot<WM>(srow + 32 * q, skp);
-        wb[q] = G::OPER + skp * G::PLANE + lds_slot<WM>(bpos<WM>(srow + 32 * q), skp);
+        wa[q] = skp * G::PLANE + (srow + 32 * q) * 16;
+        wb[q] = G::OPER + skp * G::PLANE + bpos<WM>(srow + 32 * q) * 16;
     }
+    // fragment bases: lane (fr = lane & 15, fk = lane >> 4) reads row fr (+16 m) of k-pair plane (2 kk + fk/2)
+    const int fr = lane & 15, fk = lane >> 4;
+    const int abase = (fk >> 1) * G::PLANE + (wr * 16 * WM + fr) * 16 + (fk & 1) * 8;
+    const int bbase = G::OPER + (fk >> 1) * G::PLANE + (wc * 16 * WM + fr) * 16 + (fk & 1) * 8;
 
     const int nk = (kend - kbeg) / BK;
     if (nk <= 0) return;
+    const int knob = c_knob;
+    if ((knob & 2) && (blockIdx.x & 1)) {                 // stagger: odd workgroups start half a stage late
+        __builtin_amdgcn_s_sleep(32);
+    }
 
 #pragma unroll
     for (int q = 0; q < WM; q++) {
@@ -104,46 +139,36 @@ __device__ __forceinline__ void tile_nt(const double* __restrict__ Ag, int lda, 
     }
     __syncthreads();
 
-    const int fr = lane & 15, fk = lane >> 4;            // fragment row within 16, k within 4
-    const int fhi = fk >> 1, flo = (fk & 1) * 8;
+    // two stages per trip so both LDS buffers are compile-time offsets (no address arithmetic in the loop)
+#define CUGP_STAGE(HALF, MORE, KNEXT)                                                              \
+    do {                                                                                           \
+        const char* cur_ = smem + (HALF) * G::STAGE;                                               \
+        char* nxt_ = smem + (1 - (HALF)) * G::STAGE;                                               \
+        const bool more_ = (MORE);                                                                 \
+        if (more_) {                                                                               \
+            const int k_ = (KNEXT);                                                                \
+            _Pragma("unroll") for (int q = 0; q < WM; q++) {                                       \
+                ra[q] = *(const d2*)(ag + (size_t)(32 * q) * lda + k_);                            \
+                rb[q] = *(const d2*)(bg + (size_t)(32 * q) * ldb + k_);                            \
+            }                                                                                      \
+        }                                                                                          \
+        tile_stage_mma<WM>(cur_, abase, bbase, acc, knob);                                         \
+        if (more_) {                                                                               \
+            _Pragma("unroll") for (int q = 0; q < WM; q++) {                                       \
+                *(d2*)(nxt_ + wa[q]) = NEGA ? -ra[q] : ra[q];                                      \
+                *(d2*)(nxt_ + wb[q]) = rb[q];                                                      \
+            }                                                                                      \
+        }                                                                                          \
+        __syncthreads();                                                                           \
+    } while (0)
 
-    for (int kt = 0; kt < nk; kt++) {
-        char* cur = smem + (kt & 1) * G::STAGE;
-        char* nxt = smem + ((kt + 1) & 1) * G::STAGE;
-        const bool more = (kt + 1 < nk);
-        if (more) {
-            const int k = kbeg + (kt + 1) * BK;
-#pragma unroll
-            for (int q = 0; q < WM; q++) {
-                ra[q] = *(const d2*)(ag + (size_t)(32 * q) * lda + k);
-                rb[q] = *(const d2*)(bg + (size_t)(32 * q) * ldb + k);
-            }
-        }
-#pragma unroll
-        for (int kk = 0; kk < BK / 4; kk++) {
-            const int p = kk * 2 + fhi;
-            double a[WM], b[WM];
-#pragma unroll
-            for (int m = 0; m < WM; m++) {
-                a[m] = *(const double*)(cur + p * G::PLANE + lds_slot<WM>(wr * 16 * WM + m * 16 + fr, p) + flo);
-                b[m] = *(const double*)(cur + G::OPER + p * G::PLANE + lds_slot<WM>(wc * 16 * WM + m * 16 + fr, p) +
-                                        flo);
-            }
-#pragma unroll
-            for (int m = 0; m < WM; m++)
-#pragma unroll
-                for (int n = 0; n < WM; n++)
-                    acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
-        }
-        if (more) {
-#pragma unroll
-            for (int q = 0; q < WM; q++) {
-                *(d2*)(nxt + wa[q]) = NEGA ? -ra[q] : ra[q];
-                *(d2*)(nxt + wb[q]) = rb[q];
-            }
-        }
-        __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        CUGP_STAGE(0, true, kbeg + (kt + 1) * BK);
+        CUGP_STAGE(1, kt + 2 < nk, kbeg + (kt + 2) * BK);
     }
+    if (kt < nk) CUGP_STAGE(0, false, 0);
+#undef CUGP_STAGE
 }
 
 template <int WM>
@@ -251,40 +276,12 @@ __device__ __forceinline__ void tri_index(int idx, int& ti, int& tj)
     tj = idx - r * (r + 1) / 2;
 }
 
-// ---- Cholesky panel: L21 = A21 * T11^T (T11 = inverse of the diagonal factor block), in place ----
-__global__ __launch_bounds__(256, 2) void k_trsm_panel(double* __restrict__ A, const double* __restrict__ T,
-                                                       int ld, int kb)
-{
-    __shared__ __attribute__((aligned(16))) char smem[GEMM_LDS];
-    const int k0 = kb * TILE;
-    const int i0 = (kb + 1 + blockIdx.x) * TILE;
-    d4 acc[4][4];
-    acc_zero(acc);
-    // whole 128-deep k range is read into LDS before the first store, so in place is safe
-    tile_nt<false>(A + (size_t)i0 * ld + k0, ld, T + (size_t)k0 * ld + k0, ld, 0, TILE, acc, smem);
-    tile_store(A + (size_t)i0 * ld + k0, ld, acc, 1.0);
-}
-
-// ---- Cholesky trailing update: A22(lower tiles) -= L21 * L21^T ----
-__global__ __launch_bounds__(256, 2) void k_syrk_trail(double* __restrict__ A, int ld, int kb, int first)
-{
-    __shared__ __attribute__((aligned(16))) char smem[GEMM_LDS];
-    int ti, tj;
-    tri_index(blockIdx.x + first, ti, tj);
-    const int k0 = kb * TILE;
-    const int i0 = (kb + 1 + ti) * TILE, j0 = (kb + 1 + tj) * TILE;
-    d4 acc[4][4];
-    tile_load(A + (size_t)i0 * ld + j0, ld, acc);
-    tile_nt<true>(A + (size_t)i0 * ld + k0, ld, A + (size_t)j0 * ld + k0, ld, 0, TILE, acc, smem);
-    tile_store(A + (size_t)i0 * ld + j0, ld, acc, 1.0);
-}
-
 // ---- K^-1 (lower tiles, diagonal tiles complete) = U * U^T, U = L^-T upper ----
 template <int WM>
 __global__ __launch_bounds__(256, 2) void k_lauum(const double* __restrict__ U, double* __restrict__ Kinv, int ld,
                                                   int nt)
 {
-    __shared__ __attribute__((aligned(16))) char smem[Geo<WM>::LDS];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SUB = 4 / WM, BT = 32 * WM;
     int ti, tj;
     tri_index(blockIdx.x / (SUB * SUB), ti, tj);       // ascending ti = longest k ranges first
@@ -304,7 +301,7 @@ template <int WM>
 __global__ __launch_bounds__(256, 2) void k_trtri_level(const double* __restrict__ L, double* __restrict__ T,
                                                         double* __restrict__ U, int ld, int nt, int s, int step)
 {
-    __shared__ __attribute__((aligned(16))) char smem[Geo<WM>::LDS];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SUB = 4 / WM;                          // output sub-tiles per 128-tile edge (1 or 2)
     constexpr int BT = 32 * WM;
     const int blk = blockIdx.x / (SUB * SUB), sub = blockIdx.x % (SUB * SUB);
@@ -341,7 +338,7 @@ __global__ __launch_bounds__(256, 2) void k_trtri_level(const double* __restrict
 __global__ __launch_bounds__(256, 2) void k_predict_gemm(const double* __restrict__ Ks, const double* __restrict__ T,
                                                          double* __restrict__ W, int ld, int ntt, int nt)
 {
-    __shared__ __attribute__((aligned(16))) char smem[GEMM_LDS];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tt = blockIdx.x % ntt, ti = blockIdx.x / ntt;
     d4 acc[4][4];
     acc_zero(acc);
@@ -353,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void k_predict_gemm(const double* __restric
 __global__ __launch_bounds__(256, 2) void k_test_gemm(const double* __restrict__ A, const double* __restrict__ B,
                                                       double* __restrict__ C, int n, int k, int mt)
 {
-    __shared__ __attribute__((aligned(16))) char smem[GEMM_LDS];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int ti = blockIdx.x % mt, tj = blockIdx.x / mt;
     d4 acc[4][4];
     acc_zero(acc);
@@ -902,11 +899,6 @@ __device__ __forceinline__ void diag_update_wave(double* __restrict__ A, int ld,
     for (int r = 0; r < 4; r++) C[(size_t)(4 * r) * ld] = acc[r];
 }
 
-__global__ __launch_bounds__(256) void k_syrk_diag(double* __restrict__ A, int ld, int kb)
-{
-    diag_update_wave(A, ld, kb, blockIdx.x * 4 + (threadIdx.x >> 6));
-}
-
 // ------------------------------------------------------------------------------------------
 // One launch per factorisation step kb: the trailing update A22 -= L21 L21^T AND, inside it, the
 // factorisation of the NEXT diagonal block.  Workgroups 0..8 (dispatched first) update the 36 micro
@@ -916,7 +908,8 @@ __global__ __launch_bounds__(256) void k_syrk_diag(double* __restrict__ A, int l
 // latency-bound diagonal block therefore never waits for a free CU slot and needs no second stream.
 // ------------------------------------------------------------------------------------------
 constexpr int NDIAGWG = NLT / 4;                      // 9 workgroups x 4 waves = 36 micro tiles
-constexpr int STEP_LDS = POTF2_LDS;                   // >= GEMM_LDS; two such workgroups still fit one CU
+constexpr int STEP_LDS = POTF2_LDS;                   // >= GEMM_LDS (66048); two such workgroups still fit one CU
+static_assert(POTF2_LDS >= GEMM_LDS, "the fused step kernel sizes its LDS for both roles");
 
 __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, int ld, int kb,
                                                       double* __restrict__ d16, double* __restrict__ d64,
@@ -976,52 +969,6 @@ __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, in
         tile_load<true>(A + (size_t)i0 * ld + j0, ld, acc);
         tile_nt<true>(A + (size_t)i0 * ld + k0, ld, A + (size_t)j0 * ld + k0, ld, 0, TILE, acc, (char*)sm);
         tile_store<true>(A + (size_t)i0 * ld + j0, ld, acc, 1.0);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// panel solve L21 = A21 L11^-T by block substitution on 16-row strips, ONE WAVE per strip, no LDS:
-//   X_j^T = D_j ( A_j^T - sum_{k<j} L_jk X_k^T ),  j = 0..7   (D_j = inverse of the 16x16 diagonal factor)
-// Everything is kept transposed so an MFMA result (C/D layout) is directly the B operand of the
-// next MFMA with the k index mapped as k = (lane>>4) + 4*reg; the A operands (L_jk, D_j) are read
-// from global/L2 with the same map.  144 MFMAs per strip, strips are independent.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_trsm_strips(double* __restrict__ A, const double* __restrict__ d16,
-                                                     int ld, int kb, int nstrips)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int strip = blockIdx.x * 4 + wave;
-    if (strip >= nstrips) return;
-    const int k0 = kb * TILE;
-    const int c = lane & 15, g = lane >> 4;
-    double* Arow = A + (size_t)(k0 + TILE + strip * MT + c) * ld + k0;     // my row of the strip
-    const double* L = A + (size_t)k0 * ld + k0;                             // diagonal factor block
-    const double* D = d16 + (size_t)kb * NMT * (MT * MT);
-    d4 X[NMT];
-#pragma unroll
-    for (int j = 0; j < NMT; j++) {
-        d4 z;
-#pragma unroll
-        for (int r = 0; r < 4; r++) z[r] = Arow[j * MT + g + 4 * r];
-#pragma unroll
-        for (int k = 0; k < NMT; k++) {
-            if (k < j) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const double a = -L[(size_t)(j * MT + c) * ld + k * MT + g + 4 * r];
-                    z = __builtin_amdgcn_mfma_f64_16x16x4f64(a, X[k][r], z, 0, 0, 0);
-                }
-            }
-        }
-        d4 y = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const double a = D[j * (MT * MT) + c * MT + g + 4 * r];
-            y = __builtin_amdgcn_mfma_f64_16x16x4f64(a, z[r], y, 0, 0, 0);
-        }
-        X[j] = y;
-#pragma unroll
-        for (int r = 0; r < 4; r++) Arow[j * MT + g + 4 * r] = y[r];
     }
 }
 
@@ -1262,7 +1209,12 @@ __global__ __launch_bounds__(256) void k_predict_finish(const double* __restrict
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-int g_tune[TUNE_COUNT] = {768, 1200, 384};   // defaults chosen by interleaved A/B runs (tools/ab.py)
+int g_tune[TUNE_COUNT] = {768, 1200, 384, 0};
+
+void apply_knob()
+{
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(c_knob), &g_tune[TUNE_KNOB], sizeof(int));
+}   // defaults chosen by interleaved A/B runs (tools/ab.py)
 
 static inline int tri_count(int n) { return n * (n + 1) / 2; }
 
@@ -1290,6 +1242,9 @@ static void set_big_lds()
     if (g_attr_done) return;
     (void)hipFuncSetAttribute((const void*)k_potf2, hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_LDS);
     (void)hipFuncSetAttribute((const void*)k_syrk_step, hipFuncAttributeMaxDynamicSharedMemorySize, STEP_LDS);
+    const void* gemm4[] = {(const void*)k_trtri_level<4>, (const void*)k_lauum<4>, (const void*)k_predict_gemm,
+                           (const void*)k_test_gemm};
+    for (const void* f : gemm4) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
     (void)hipFuncSetAttribute((const void*)k_trtri_diag, hipFuncAttributeMaxDynamicSharedMemorySize, TRTRI_LDS);
     g_attr_done = true;
 }
@@ -1314,28 +1269,6 @@ void launch_trtri_diag(const double* A, int ld, int kb, int nblocks, const doubl
     hipLaunchKernelGGL(k_trtri_diag, dim3(nblocks), dim3(256), TRTRI_LDS, s, A, ld, kb, d16, T, U);
 }
 
-void launch_trsm_panel(double* A, const double* T, int ld, int kb, int nt, hipStream_t s)
-{
-    const int m = nt - kb - 1;
-    if (m <= 0) return;
-    hipLaunchKernelGGL(k_trsm_panel, dim3(m), dim3(256), 0, s, A, T, ld, kb);
-}
-
-void launch_trsm_strips(double* A, const double* d16, int ld, int kb, int nt, hipStream_t s)
-{
-    const int nstrips = (nt - kb - 1) * (TILE / MT);
-    if (nstrips <= 0) return;
-    hipLaunchKernelGGL(k_trsm_strips, dim3((nstrips + 3) / 4), dim3(256), 0, s, A, d16, ld, kb, nstrips);
-}
-
-void launch_syrk_trail(double* A, int ld, int kb, int nt, bool skip_next_diag, hipStream_t s)
-{
-    const int m = nt - kb - 1;
-    const int first = skip_next_diag ? 1 : 0;          // tile 0 = (kb+1, kb+1), done by launch_syrk_diag
-    if (tri_count(m) - first <= 0) return;
-    hipLaunchKernelGGL(k_syrk_trail, dim3(tri_count(m) - first), dim3(256), 0, s, A, ld, kb, first);
-}
-
 void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* d64, double* logdet_part,
                       unsigned* tickets, hipStream_t s)
 {
@@ -1351,11 +1284,6 @@ void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* d6
                        d64, logdet_part, tickets, nfull);
 }
 
-void launch_syrk_diag(double* A, int ld, int kb, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_syrk_diag, dim3(NLT / 4), dim3(256), 0, s, A, ld, kb);
-}
-
 void launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, int s, int step, hipStream_t st)
 {
     // pairs p = 0.. : A = [2ps, 2ps+s), B = [2ps+s, min(2ps+2s, nt)); count tiles |A| x |B|
@@ -1367,23 +1295,26 @@ void launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, i
     }
     if (tiles <= 0) return;
     // few 128-tiles cannot fill 512 workgroup slots: use 64x64 output tiles (4x the parallelism) there
+    set_big_lds();
     if (tiles <= g_tune[TUNE_TRTRI_WM2_MAX])
-        hipLaunchKernelGGL(k_trtri_level<2>, dim3(tiles * 4), dim3(256), 0, st, L, T, U, ld, nt, s, step);
+        hipLaunchKernelGGL(k_trtri_level<2>, dim3(tiles * 4), dim3(256), Geo<2>::LDS, st, L, T, U, ld, nt, s, step);
     else
-        hipLaunchKernelGGL(k_trtri_level<4>, dim3(tiles), dim3(256), 0, st, L, T, U, ld, nt, s, step);
+        hipLaunchKernelGGL(k_trtri_level<4>, dim3(tiles), dim3(256), GEMM_LDS, st, L, T, U, ld, nt, s, step);
 }
 
 void launch_lauum(const double* U, double* Kinv, int ld, int nt, hipStream_t s)
 {
+    set_big_lds();
     if (tri_count(nt) <= g_tune[TUNE_LAUUM_WM2_MAX])
-        hipLaunchKernelGGL(k_lauum<2>, dim3(tri_count(nt) * 4), dim3(256), 0, s, U, Kinv, ld, nt);
+        hipLaunchKernelGGL(k_lauum<2>, dim3(tri_count(nt) * 4), dim3(256), Geo<2>::LDS, s, U, Kinv, ld, nt);
     else
-        hipLaunchKernelGGL(k_lauum<4>, dim3(tri_count(nt)), dim3(256), 0, s, U, Kinv, ld, nt);
+        hipLaunchKernelGGL(k_lauum<4>, dim3(tri_count(nt)), dim3(256), GEMM_LDS, s, U, Kinv, ld, nt);
 }
 
 void launch_predict_gemm(const double* Ks, const double* T, double* W, int ld, int ntt, int nt, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_predict_gemm, dim3(ntt * nt), dim3(256), 0, s, Ks, T, W, ld, ntt, nt);
+    set_big_lds();
+    hipLaunchKernelGGL(k_predict_gemm, dim3(ntt * nt), dim3(256), GEMM_LDS, s, Ks, T, W, ld, ntt, nt);
 }
 
 void launch_predict_finish(const double* Ks, const double* W, const double* alpha, int n, int npad, int ntest,
@@ -1432,7 +1363,8 @@ void launch_finalize(const double* z, int npad, int n, const double* logdet_part
 
 void launch_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, int k, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_test_gemm, dim3((m / TILE) * (n / TILE)), dim3(256), 0, s, A, B, C, n, k, m / TILE);
+    set_big_lds();
+    hipLaunchKernelGGL(k_test_gemm, dim3((m / TILE) * (n / TILE)), dim3(256), GEMM_LDS, s, A, B, C, n, k, m / TILE);
 }
 
 void launch_mfma_peak(double* sink, int blocks, int iters, hipStream_t s)

@@ -58,17 +58,13 @@ int main()
     printf("  tail wait %llu | store+last inverse %llu | logdet %llu | 64x64 inverses %llu | total %llu cycles\n",
            st[30] - st[23], st[31] - st[30], st[32] - st[31], st[33] - st[32], st[33] - st[0]);
 
-    auto trsm = [](void* p) { Ctx* c = (Ctx*)p; launch_trsm_strips(c->A, c->d16, c->n, 0, c->nt, 0); };
-    printf("trsm_strips (%d strips): %.2f us\n", (nt - 1) * 8, timeit(trsm, &c, 50));
     auto trsm2 = [](void* p) { Ctx* c = (Ctx*)p; launch_trsm_inv64(c->A, c->d64, c->n, 0, c->nt, 0); };
     printf("trsm_inv64 (%d strips): %.2f us\n", (nt - 1) * 8, timeit(trsm2, &c, 50));
-    auto sd = [](void* p) { Ctx* c = (Ctx*)p; launch_syrk_diag(c->A, c->n, 0, 0); };
-    printf("syrk_diag: %.2f us\n", timeit(sd, &c, 50));
-    auto st1 = [](void* p) { Ctx* c = (Ctx*)p; launch_syrk_trail(c->A, c->n, 0, c->nt, true, 0); };
-    printf("syrk_trail (%d tiles): %.2f us\n", 15 * 16 / 2 - 1, timeit(st1, &c, 20));
-    auto st2 = [](void* p) { Ctx* c = (Ctx*)p; launch_syrk_trail(c->A, c->n, 13, c->nt, false, 0); };
-    printf("syrk_trail (3 tiles): %.2f us\n", timeit(st2, &c, 20));
-    auto empty = [](void* p) { Ctx* c = (Ctx*)p; launch_trsv_lower(c->A, c->A, c->n, 0, c->A, c->A, 0); };
-    (void)empty;
+    unsigned* tk; hipMalloc(&tk, nt * 4);
+    struct C2 { Ctx* c; unsigned* tk; int kb; } c2{&c, tk, 0}, c3{&c, tk, 12};
+    auto step = [](void* p) { C2* q = (C2*)p; hipMemsetAsync(q->tk, 0, q->c->nt * 4, 0);
+                              launch_syrk_step(q->c->A, q->c->n, q->kb, q->c->nt, q->c->d16, q->c->d64, q->c->ld, q->tk, 0); };
+    printf("syrk_step kb=0 (119 tiles + next diagonal block): %.2f us\n", timeit(step, &c2, 20));
+    printf("syrk_step kb=12 (5 tiles + next diagonal block): %.2f us\n", timeit(step, &c3, 20));
     return 0;
 }

@@ -4,8 +4,8 @@
 #include <cstdio>
 typedef double d4 __attribute__((ext_vector_type(4)));
 
-template <int LDS>
-__global__ __launch_bounds__(256) void k(double* sink, int iters, unsigned long long* clk)
+template <int LDS, int FILL>
+__global__ __launch_bounds__(256, 2) void k(double* sink, int iters, unsigned long long* clk)
 {
     __shared__ double sm[2048];
     d4 acc[4][4];
@@ -31,10 +31,16 @@ __global__ __launch_bounds__(256) void k(double* sink, int iters, unsigned long 
 #pragma unroll
             for (int m = 0; m < 4; m++) { a[m] += 1e-12; b[m] -= 1e-12; }
         }
+        int filler = it;
 #pragma unroll
         for (int m = 0; m < 4; m++)
 #pragma unroll
-            for (int n = 0; n < 4; n++) acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+            for (int n = 0; n < 4; n++) {
+                acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+                for (int f = 0; f < FILL; f++) asm volatile("v_add_u32 %0, %0, 1" : "+v"(filler));
+            }
+        if (filler == -12345) sink[0] = filler;
     }
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
     double s = 0;
@@ -57,15 +63,18 @@ template <typename F> void run(const char* name, F launch, int blocks, int iters
     unsigned long long h; hipMemcpy(&h, clk, 8, hipMemcpyDeviceToHost);
     double tf = (double)blocks * 4 * iters * 16 * 2048.0 / (ms * 1e-3) / 1e12;
     int wps = blocks / 256;
-    printf("%-22s waves/SIMD=%d  %.1f TFLOP/s  cycles per MFMA per SIMD = %.1f\n", name, wps, tf, (double)h / iters / 16 / wps);
+    printf("%-22s waves/SIMD=%d  %.1f TFLOP/s (wall)  in-kernel cycles per MFMA per wave = %.1f\n", name, wps, tf, (double)h / iters / 16);
     hipFree(sink); hipFree(clk);
 }
 int main()
 {
-    for (int wps : {1, 2, 3}) {
+    for (int wps : {1, 2}) {
         int blocks = 256 * wps;
-        run("regs only", [&](double* s, int i, unsigned long long* c) { hipLaunchKernelGGL(k<0>, dim3(blocks), dim3(256), 0, 0, s, i, c); }, blocks, 4000);
-        run("LDS operand reads", [&](double* s, int i, unsigned long long* c) { hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), 0, 0, s, i, c); }, blocks, 4000);
+        run("regs only", [&](double* s, int i, unsigned long long* c) { hipLaunchKernelGGL((k<0, 0>), dim3(blocks), dim3(256), 0, 0, s, i, c); }, blocks, 4000);
+        run("LDS operand reads", [&](double* s, int i, unsigned long long* c) { hipLaunchKernelGGL((k<1, 0>), dim3(blocks), dim3(256), 0, 0, s, i, c); }, blocks, 4000);
+        run("regs + 1 VALU/MFMA", [&](double* s, int i, unsigned long long* c) { hipLaunchKernelGGL((k<0, 1>), dim3(blocks), dim3(256), 0, 0, s, i, c); }, blocks, 4000);
+        run("regs + 4 VALU/MFMA", [&](double* s, int i, unsigned long long* c) { hipLaunchKernelGGL((k<0, 4>), dim3(blocks), dim3(256), 0, 0, s, i, c); }, blocks, 4000);
+        run("LDS + 2 VALU/MFMA", [&](double* s, int i, unsigned long long* c) { hipLaunchKernelGGL((k<1, 2>), dim3(blocks), dim3(256), 0, 0, s, i, c); }, blocks, 4000);
     }
     return 0;
 }
