@@ -80,6 +80,7 @@ SIGNATURES = {
     "cugp_test_gemm_nt": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int]),
     "cugp_mfma_peak_tflops": (C.c_int, [C.c_int, _dp]),
     "cugp_set_tuning": (C.c_int, [C.c_int, C.c_int]),
+    "cugp_bench_la": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
 }
 
 _lib = None

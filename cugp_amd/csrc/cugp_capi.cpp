@@ -764,6 +764,52 @@ int cugp_test_gemm_nt(int m, int n, int k, const double* A, const double* B, dou
     return CUGP_OK;
 }
 
+// stand-alone dense-LA timings on a synthetic SPD matrix built on the device (no host traffic in the timed
+// region): the like-for-like counterparts of the reference's library probes cuda_src/cholesky_cu_solver.cpp
+// (cusolverDnDpotrf), tmi_cu_solver.cpp (cublasDtrsm vs identity = triangular inverse) and
+// cublas_matrix_multiply.cpp (cublasDgemm).  op: 0 Cholesky, 1 triangular inverse of the factor,
+// 2 K^-1 = L^-T L^-1 from the triangular inverse, 3 the three together.  ms = best of `reps`.
+int cugp_bench_la(int op, int n, int device, int reps, double* ms)
+{
+    if (!ms || n <= 0 || op < 0 || op > 4 || reps <= 0) return CUGP_ERR_INVALID;
+    cugp_gp* g = nullptr;
+    const int d = 4;
+    int rc = cugp_create(n, d, device, &g);
+    if (rc) return rc;
+    std::vector<double> X((size_t)n * d), y(n, 0.0);
+    unsigned long long st = 88172645463325252ull;                 // xorshift: reproducible inputs
+    for (double& v : X) { st ^= st << 13; st ^= st >> 7; st ^= st << 17; v = (double)(st >> 11) / 9007199254740992.0 * 6.0 - 3.0; }
+    const double hp[3] = {0.0, 0.0, -1.0};
+    if ((rc = cugp_set_data(g, X.data(), y.data())) || (rc = cugp_set_loghyper(g, hp)) ||
+        (rc = ensure_factor_bufs(g)) || (rc = ensure_inverse_bufs(g))) { cugp_destroy(g); return rc; }
+    hipEvent_t e0, e1;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    double best = 1e300;
+    for (int r = 0; r < reps + 1 && e == hipSuccess && rc == CUGP_OK; r++) {
+        launch_kbuild(g->dX, g->n, g->d, g->npad, scalars(g), g->dA, op == 4, g->stream);
+        if (op == 1 || op == 2) rc = enqueue_potrf(g);
+        if (op == 2 && !rc) rc = enqueue_trtri(g);
+        if (rc) break;
+        e = hipEventRecord(e0, g->stream);
+        if (op == 4) launch_test_gemm_nt(g->dA, g->dA, g->dKinv, g->npad, g->npad, g->npad, g->stream);   // uniform tiles
+        if (op == 0 || op == 3) rc = enqueue_potrf(g);
+        if ((op == 1 || op == 3) && !rc) rc = enqueue_trtri(g);
+        if ((op == 2 || op == 3) && !rc) launch_lauum(g->dU, g->dKinv, g->npad, g->nt, g->stream);
+        if (e == hipSuccess) e = hipEventRecord(e1, g->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float t = 0;
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, e0, e1);
+        if (r > 0 && t < best) best = t;                          // first round warms up
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    cugp_destroy(g);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(CUGP_ERR_DEVICE, "cugp_bench_la", e);
+    *ms = best;
+    return CUGP_OK;
+}
+
 int cugp_mfma_peak_tflops(int device, double* tflops)
 {
     if (!tflops) return CUGP_ERR_INVALID;

@@ -150,6 +150,10 @@ int cugp_bcm_cg_solve(cugp_bcm *b, int budget, double *trace, int trace_cap, int
 /* ---- test / bench hooks ---- */
 int cugp_test_gemm_nt(int m, int n, int k, const double *A, const double *B, double *C, int device);
 int cugp_mfma_peak_tflops(int device, double *tflops);
+/* stand-alone LA timings on a device-built SPD matrix (ms, best of reps): op 0 Cholesky (cuda_src/
+ * cholesky_cu_solver.cpp), 1 triangular inverse of the factor (tmi_cu_solver.cpp), 2 K^-1 from it, 3 all three,
+ * 4 plain C = K K^T with uniform tiles (cublas_matrix_multiply.cpp) */
+int cugp_bench_la(int op, int n, int device, int reps, double *ms);
 int cugp_set_tuning(int key, int value);     /* launch-shape thresholds (kernels.h TUNE_*), for A/B runs */
 
 #ifdef __cplusplus
