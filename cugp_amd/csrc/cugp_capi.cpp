@@ -742,7 +742,6 @@ int cugp_set_tuning(int key, int value)
 {
     if (key < 0 || key >= TUNE_COUNT) return CUGP_ERR_INVALID;
     g_tune[key] = value;
-    if (key == TUNE_KNOB) apply_knob();
     return CUGP_OK;
 }
 

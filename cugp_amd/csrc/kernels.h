@@ -11,9 +11,7 @@ constexpr int TILE = 128;          // tile edge of every fp64 MFMA product and o
 enum { TUNE_LAUUM_WM2_MAX = 0,   // K^-1 product: use 64x64 tiles when there are at most this many 128-tiles
        TUNE_TRTRI_WM2_MAX = 1,   // inverse level: same rule
        TUNE_SYRK_REM_MAX = 2,    // trailing update: split the last partial round into 64x64 quarters when it has at most this many tiles
-       TUNE_KNOB = 3,            // bit 0: s_setprio(1) around MFMA blocks; bit 1: stagger odd workgroups
-       TUNE_COUNT = 4 };
-void apply_knob();
+       TUNE_COUNT = 3 };
 extern int g_tune[TUNE_COUNT];
 
 struct HyperScalars {              // exp(2*theta) evaluated on the host, as the reference does (covkernel.cpp:65-67)

@@ -13,9 +13,10 @@
 //   C[128x128] = sum_k A[i][k] * B[j][k]   ("NT": both operands row-major with k contiguous)
 // 4 waves per workgroup in a 2x2 grid, 64x64 per wave = 4x4 MFMA tiles (64 fp64 accumulators
 // per lane), K staged 16 deep through LDS, double-buffered, global loads for stage t+1 in
-// flight while stage t is multiplied.  LDS image: [k-pair plane][row rotated by plane][2 doubles]
-// -- fragment reads are 256 contiguous bytes per 32 lanes (conflict-free ds_read_b64), staging
-// writes (8 lanes = 8 planes of one row) land on 8 different 16-B slots (conflict-free b128).
+// flight while stage t is multiplied.  LDS image: [k-pair plane, padded by 16 B][row][2 doubles]
+// -- fragment reads are 256 contiguous bytes per 32 lanes (conflict-free ds_read_b64) at one
+// per-lane base + immediate offsets (no address arithmetic in the loop: VALU issue costs MFMA
+// issue on gfx950), staging writes (8 lanes = 8 planes of one row) land on 8 different 16-B slots.
 //
 // Matrices are npad x npad row-major with npad = ceil(n/128)*128; the padding of K is the
 // identity, so every kernel works on whole tiles and the factor, inverse, log-determinant and
@@ -66,14 +67,11 @@ __device__ __forceinline__ int bpos(int R)
 // One K stage (16 deep) of MFMAs out of LDS buffer `cur`.  Measured on gfx950: every VALU instruction a wave
 // issues between fp64 MFMAs costs MFMA issue time (pure MFMA stream 74 TF/s, +1 VALU per MFMA 62, +4: 55),
 // so the loop body carries NO address arithmetic: fragment addresses are one per-lane base + immediates.
-__constant__ int c_knob;      // run-time A/B switch for kernel-internal variants (cugp_set_tuning key 3)
-
 template <int WM>
 __device__ __forceinline__ void tile_stage_mma(const char* __restrict__ cur, int abase, int bbase,
-                                               d4 (&acc)[WM][WM], int knob)
+                                               d4 (&acc)[WM][WM])
 {
     typedef Geo<WM> G;
-    if (knob & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kk = 0; kk < BK / 4; kk++) {
         double a[WM], b[WM];
@@ -88,7 +86,6 @@ __device__ __forceinline__ void tile_stage_mma(const char* __restrict__ cur, int
             for (int n = 0; n < WM; n++)
                 acc[m][n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n], acc[m][n], 0, 0, 0);
     }
-    if (knob & 1) __builtin_amdgcn_s_setprio(0);
 }
 
 // acc[m][n] += (NEGA ? -1 : 1) * A(i0.., kbeg..kend) * B(j0.., kbeg..kend)^T ; Ag -> A[i0][0], Bg -> B[j0][0];
@@ -122,10 +119,6 @@ __device__ __forceinline__ void tile_nt(const double* __restrict__ Ag, int lda, 
 
     const int nk = (kend - kbeg) / BK;
     if (nk <= 0) return;
-    const int knob = c_knob;
-    if ((knob & 2) && (blockIdx.x & 1)) {                 // stagger: odd workgroups start half a stage late
-        __builtin_amdgcn_s_sleep(32);
-    }
 
 #pragma unroll
     for (int q = 0; q < WM; q++) {
@@ -152,7 +145,7 @@ __device__ __forceinline__ void tile_nt(const double* __restrict__ Ag, int lda, 
                 rb[q] = *(const d2*)(bg + (size_t)(32 * q) * ldb + k_);                            \
             }                                                                                      \
         }                                                                                          \
-        tile_stage_mma<WM>(cur_, abase, bbase, acc, knob);                                         \
+        tile_stage_mma<WM>(cur_, abase, bbase, acc);                                               \
         if (more_) {                                                                               \
             _Pragma("unroll") for (int q = 0; q < WM; q++) {                                       \
                 *(d2*)(nxt_ + wa[q]) = NEGA ? -ra[q] : ra[q];                                      \
@@ -1209,12 +1202,7 @@ __global__ __launch_bounds__(256) void k_predict_finish(const double* __restrict
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-int g_tune[TUNE_COUNT] = {768, 1200, 384, 0};
-
-void apply_knob()
-{
-    (void)hipMemcpyToSymbol(HIP_SYMBOL(c_knob), &g_tune[TUNE_KNOB], sizeof(int));
-}   // defaults chosen by interleaved A/B runs (tools/ab.py)
+int g_tune[TUNE_COUNT] = {768, 1200, 384};   // defaults chosen by interleaved A/B runs (tools/ab.py)
 
 static inline int tri_count(int n) { return n * (n + 1) / 2; }
 

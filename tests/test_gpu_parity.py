@@ -148,8 +148,8 @@ def test_sine_golden(gp_mod, sine, golden_sine, idx):
         assert np.allclose(v, c["pred_var"], rtol=1e-8, atol=1e-8)
 
 
-@pytest.mark.parametrize("n,d", [(96, 3), (300, 10), (515, 7)])
-def test_live_oracle(gp_mod, oracle, n, d):
+@pytest.mark.parametrize("n,d,nt", [(64, 1, 3), (96, 3, 9), (300, 10, 150), (515, 7, 9)])
+def test_live_oracle(gp_mod, oracle, n, d, nt):
     X, y = synth(n, d=d, seed=n, scale=3.0)
     hp = [1.1, 0.3, -0.8]
     g = gp_mod.Covsum(n, d)
@@ -157,7 +157,7 @@ def test_live_oracle(gp_mod, oracle, n, d):
     ll, gr = g.loglik_grad(X, y)
     llo, gro = oracle.loglik_grad(X, y, hp)
     assert ll_close(ll, llo) and vec_close(gr, gro)
-    Xt = synth(9, d=d, seed=7, scale=3.0)[0]
+    Xt = synth(nt, d=d, seed=7, scale=3.0)[0]        # nt = 150 spans two 128-row tiles of test points
     m, v = g.compute_test_means_and_variances(X, y, Xt)
     mo, vo = oracle.predict(X, y, hp, Xt)
     assert np.allclose(m, mo, rtol=1e-8, atol=1e-8) and np.allclose(v, vo, rtol=1e-8, atol=1e-8)
