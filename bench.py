@@ -68,6 +68,10 @@ def main():
     ap.add_argument("--rows", dest="n", type=int, default=N_METRIC, help="rows per expert (metric config: 8192)")
     ap.add_argument("--dims", dest="d", type=int, default=D_METRIC)
     ap.add_argument("--experts-per-gpu", type=int, default=1)
+    ap.add_argument("--experts-total", type=int, default=0,
+                    help="strong-scaling BCM workload: this many experts in total, expert k on rank k mod N "
+                         "(e.g. --experts-total 16 --rows 1500 = the si24000 16-shard shape); value = BCM objective "
+                         "evaluations/s (all experts + all-reduce per evaluation)")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="rows for the CPU baseline (0 = skip)")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path on a box with fewer GPUs than ranks)")
@@ -99,7 +103,8 @@ def main():
 
     from cugp_amd.bcm import ShardedBCM
 
-    K = world * args.experts_per_gpu
+    strong = args.experts_total > 0
+    K = args.experts_total if strong else world * args.experts_per_gpu
     experts = [None] * K
     for k in range(K):
         if k % world == rank:
@@ -139,17 +144,21 @@ def main():
     npad = -(-args.n // 128) * 128
 
     if rank == 0:
-        evals = args.steps * K
+        evals = args.steps * (1 if strong else K)
         out = {
-            "metric": "GP log-lik+grad evals/sec (N=%d, D=%d)" % (args.n, args.d),
+            "metric": ("BCM log-lik+grad evals/sec (%d experts x N=%d, D=%d)" % (K, args.n, args.d)) if strong
+            else "GP log-lik+grad evals/sec (N=%d, D=%d)" % (args.n, args.d),
             "value": evals / dt, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "gp_loglik_grad_N%d_D%d" % (args.n, args.d), "experts": K,
-                       "experts_per_gpu": args.experts_per_gpu, "sharding": "bcm-experts-per-gpu",
+            "config": {"workload": ("bcm_%dx%d_D%d" % (K, args.n, args.d)) if strong
+                       else "gp_loglik_grad_N%d_D%d" % (args.n, args.d), "experts": K,
+                       "experts_per_gpu": (K + world - 1) // world if strong else args.experts_per_gpu,
+                       "sharding": "bcm-experts-per-gpu",
                        "hp": HP0.tolist()},
             "cholesky_gflops": (npad ** 3 / 3.0) / (ph["potrf"] * 1e-3) / 1e9,
-            "eval_tflops_n3": (float(args.n) ** 3) / (dt / (args.steps * args.experts_per_gpu)) / 1e12,
+            "eval_tflops_n3": (float(args.n) ** 3) * (K if strong else world * args.experts_per_gpu) / world
+                              / (dt / args.steps) / 1e12,
             "phase_ms_last": {k: round(v, 4) for k, v in ph.items()},
             "ll_last": ll, "grad_last": [float(v) for v in g],
         }
