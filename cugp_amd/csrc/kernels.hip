@@ -388,37 +388,51 @@ __global__ __launch_bounds__(256) void k_trsm_inv64(double* __restrict__ A, cons
     const d4 zero4 = (d4){0.0, 0.0, 0.0, 0.0};
 
     // phase 1: X0^T[w] = sum_{kt <= w} T00[w][kt] A0^T[kt]
-    d4 x0 = zero4;
+    // (each phase runs two independent accumulation chains: a dependent fp64 MFMA chain issues at half rate)
+    d4 x0 = zero4, x0b = zero4;
     for (int kt = 0; kt <= w; kt++) {
 #pragma unroll
-        for (int r = 0; r < 4; r++)
+        for (int r = 0; r < 4; r += 2) {
             x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(T00[(w * MT + c) * 64 + kt * MT + g + 4 * r],
                                                       Arow[kt * MT + g + 4 * r], x0, 0, 0, 0);
+            x0b = __builtin_amdgcn_mfma_f64_16x16x4f64(T00[(w * MT + c) * 64 + kt * MT + g + 4 * (r + 1)],
+                                                       Arow[kt * MT + g + 4 * (r + 1)], x0b, 0, 0, 0);
+        }
     }
+    x0 += x0b;
     d4 z;
 #pragma unroll
     for (int r = 0; r < 4; r++) { xbuf[w][r][lane] = x0[r]; z[r] = Arow[64 + w * MT + g + 4 * r]; }
     __syncthreads();
     // phase 2: Z1^T[w] = A1^T[w] - sum_kt L10[w][kt] X0^T[kt]
+    d4 zb = zero4;
 #pragma unroll
     for (int kt = 0; kt < 4; kt++) {
 #pragma unroll
-        for (int r = 0; r < 4; r++)
+        for (int r = 0; r < 4; r += 2) {
             z = __builtin_amdgcn_mfma_f64_16x16x4f64(-L10[(size_t)(w * MT + c) * ld + kt * MT + g + 4 * r],
                                                      xbuf[kt][r][lane], z, 0, 0, 0);
+            zb = __builtin_amdgcn_mfma_f64_16x16x4f64(-L10[(size_t)(w * MT + c) * ld + kt * MT + g + 4 * (r + 1)],
+                                                      xbuf[kt][r + 1][lane], zb, 0, 0, 0);
+        }
     }
+    z += zb;
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < 4; r++) { xbuf[w][r][lane] = z[r]; Arow[w * MT + g + 4 * r] = x0[r]; }
     __syncthreads();
     // phase 3: X1^T[w] = sum_{kt <= w} T11[w][kt] Z1^T[kt]
-    d4 x1 = zero4;
+    d4 x1 = zero4, x1b = zero4;
     for (int kt = 0; kt <= w; kt++) {
 #pragma unroll
-        for (int r = 0; r < 4; r++)
+        for (int r = 0; r < 4; r += 2) {
             x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(T11[(w * MT + c) * 64 + kt * MT + g + 4 * r], xbuf[kt][r][lane],
                                                       x1, 0, 0, 0);
+            x1b = __builtin_amdgcn_mfma_f64_16x16x4f64(T11[(w * MT + c) * 64 + kt * MT + g + 4 * (r + 1)],
+                                                       xbuf[kt][r + 1][lane], x1b, 0, 0, 0);
+        }
     }
+    x1 += x1b;
 #pragma unroll
     for (int r = 0; r < 4; r++) Arow[64 + w * MT + g + 4 * r] = x1[r];
 }
@@ -651,17 +665,18 @@ __device__ __forceinline__ void micro_update(double* __restrict__ sm, int bi, in
     double* C = sm + mt_off(bi, bj);
     const double* Xi = sm + mt_off(bi, jb);
     const double* Xj = sm + mt_off(bj, jb);
-    d4 acc;
+    d4 acc, acc2 = (d4){0.0, 0.0, 0.0, 0.0};            // two independent chains (dependent MFMAs issue at half rate)
 #pragma unroll
     for (int r = 0; r < 4; r++) acc[r] = C[(g + 4 * r) * (MT + 1) + c];
 #pragma unroll
-    for (int s = 0; s < 4; s++) {
-        const double a = -Xi[c * (MT + 1) + 4 * s + g];
-        const double b = Xj[c * (MT + 1) + 4 * s + g];
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+    for (int s = 0; s < 4; s += 2) {
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xi[c * (MT + 1) + 4 * s + g], Xj[c * (MT + 1) + 4 * s + g], acc, 0,
+                                                   0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xi[c * (MT + 1) + 4 * (s + 1) + g],
+                                                    Xj[c * (MT + 1) + 4 * (s + 1) + g], acc2, 0, 0, 0);
     }
 #pragma unroll
-    for (int r = 0; r < 4; r++) C[(g + 4 * r) * (MT + 1) + c] = acc[r];
+    for (int r = 0; r < 4; r++) C[(g + 4 * r) * (MT + 1) + c] = acc[r] + acc2[r];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -879,17 +894,24 @@ __device__ __forceinline__ void diag_update_wave(double* __restrict__ A, int ld,
     const double* Li = A + (size_t)(i0 + bi * MT + c) * ld + k0 + g;
     const double* Lj = A + (size_t)(i0 + bj * MT + c) * ld + k0 + g;
     double* C = A + (size_t)(i0 + bi * MT + g) * ld + i0 + bj * MT + c;
-    d4 acc;
+    // four independent accumulation chains (a dependent fp64 MFMA chain issues every ~140 cycles, independent
+    // ones every ~66), summed at the end
+    d4 acc[4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) acc[r] = C[(size_t)(4 * r) * ld];
+    for (int r = 0; r < 4; r++) acc[0][r] = C[(size_t)(4 * r) * ld];
+#pragma unroll
+    for (int q = 1; q < 4; q++) acc[q] = (d4){0.0, 0.0, 0.0, 0.0};
     double la[TILE / 4], lb[TILE / 4];                 // all operands in flight before the first MFMA
 #pragma unroll
     for (int s = 0; s < TILE / 4; s++) { la[s] = Li[4 * s]; lb[s] = Lj[4 * s]; }
 #pragma unroll
     for (int s = 0; s < TILE / 4; s++)
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-la[s], lb[s], acc, 0, 0, 0);
+        acc[s & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(-la[s], lb[s], acc[s & 3], 0, 0, 0);
+    // write-through (sc1) stores: the consumer is another workgroup (guide G16: sc1 stores need no agent release)
 #pragma unroll
-    for (int r = 0; r < 4; r++) C[(size_t)(4 * r) * ld] = acc[r];
+    for (int r = 0; r < 4; r++)
+        __hip_atomic_store(C + (size_t)(4 * r) * ld, (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -914,14 +936,12 @@ __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, in
     __shared__ unsigned s_ticket;
     if (blockIdx.x < NDIAGWG) {
         diag_update_wave(A, ld, kb, blockIdx.x * 4 + (threadIdx.x >> 6));
-        // publish (cdna guide G16, counter form): drain my stores, workgroup barrier, agent release, ticket
+        // publish (cdna guide G16, counter form with write-through stores): every wave drains its sc1 stores,
+        // workgroup barrier, then ONE lane draws the ticket (no agent release needed for sc1 stores)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0)
             s_ticket = __hip_atomic_fetch_add(&tickets[kb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
         __syncthreads();
         if (s_ticket != NDIAGWG - 1) return;           // not the last arriver
         if (threadIdx.x == 0) {
