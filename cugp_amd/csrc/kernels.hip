@@ -1089,14 +1089,23 @@ __global__ __launch_bounds__(256) void k_trmv_upper(const double* __restrict__ U
 __global__ __launch_bounds__(256) void k_trsv_diag(const double* __restrict__ T, int ld, int kb,
                                                    const double* __restrict__ w, double* __restrict__ z)
 {
-    const int k0 = kb * TILE;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int r = wave; r < TILE; r += 4) {
-        const double* tr = T + (size_t)(k0 + r) * ld + k0;
-        d2 v = *(const d2*)(tr + lane * 2), xv = *(const d2*)(w + k0 + lane * 2);
-        double s = wave_sum(v[0] * xv[0] + v[1] * xv[1]);
-        if (lane == 0) z[k0 + r] = s;
+    // z_kb = T_kk w_kb (128x128, lower): two threads per row, 64 columns each, 16-byte loads
+    __shared__ double ws[TILE];
+    const int k0 = kb * TILE, t = threadIdx.x;
+    if (t < TILE) ws[t] = w[k0 + t];
+    __syncthreads();
+    const int r = t >> 1, h = t & 1;
+    const double* tr = T + (size_t)(k0 + r) * ld + k0 + h * 64;
+    double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+    for (int c = 0; c < 64; c += 2) {
+        const d2 v = *(const d2*)(tr + c);
+        s0 = __builtin_fma(v[0], ws[h * 64 + c], s0);
+        s1 = __builtin_fma(v[1], ws[h * 64 + c + 1], s1);
     }
+    double sum = s0 + s1;
+    sum += __shfl_xor(sum, 1, 64);
+    if (h == 0) z[k0 + r] = sum;
 }
 
 __global__ __launch_bounds__(256) void k_trsv_update(const double* __restrict__ A, int ld, int kb, int npad,
