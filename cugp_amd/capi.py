@@ -34,6 +34,7 @@ SIGNATURES = {
     "cugp_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "cugp_destroy": (C.c_int, [C.c_void_p]),
     "cugp_dims": (C.c_int, [C.c_void_p, _ip, _ip, _ip]),
+    "cugp_set_overlap": (C.c_int, [C.c_void_p, C.c_int]),
     "cugp_set_data": (C.c_int, [C.c_void_p, _dp, _dp]),
     "cugp_set_data_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "cugp_set_loghyper": (C.c_int, [C.c_void_p, _dp]),

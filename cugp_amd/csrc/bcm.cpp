@@ -33,6 +33,8 @@ int cugp_bcm_create(int nexperts, const int* rows, int d, int device, cugp_bcm**
         cugp_gp* g = nullptr;
         int rc = cugp_create(rows[k], d, device, &g);
         if (rc) { cugp_bcm_destroy(b); return rc; }
+        // several experts on one device already fill each other's idle time; the extra streams only cost launches
+        if (nexperts > 1) cugp_set_overlap(g, 0);
         b->experts.push_back(g);
         b->rows.push_back(rows[k]);
     }

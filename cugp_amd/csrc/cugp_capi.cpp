@@ -50,7 +50,11 @@ constexpr int MAX_KEV = 4096;   // per-launch event pairs kept between resets
 
 struct cugp_gp {
     int n = 0, d = 0, npad = 0, nt = 0, device = 0;
-    hipStream_t stream = nullptr;   // all device work of the handle is ordered here
+    hipStream_t stream = nullptr;   // all device work of the handle is ordered here ...
+    hipStream_t aux = nullptr;      // ... except the inverse blocks that run beside the factorisation (fork/join by events):
+    hipStream_t aux2 = nullptr;     // aux = the large products, aux2 = each block's own small inverse
+    std::vector<hipEvent_t> bev;    // fork events, one per inverse block, + the join event (last)
+    std::vector<hipEvent_t> oev;    // "block's own inverse done" events (aux2 -> aux)
     double *dX = nullptr, *dy = nullptr, *dA = nullptr, *dT = nullptr, *dU = nullptr, *dKinv = nullptr;
     double *dz = nullptr, *dalpha = nullptr, *dw = nullptr, *d16 = nullptr, *dlogdet = nullptr, *dpart = nullptr, *d64 = nullptr;
     double* dout = nullptr;
@@ -62,6 +66,8 @@ struct cugp_gp {
     bool factor_valid = false;     // A holds L for (data, hp)
     bool inverse_valid = false;    // T, U, Kinv, alpha hold the inverse quantities for (data, hp)
     bool pending = false, pending_grad = false;
+    bool joined = true;            // no inverse blocks outstanding on `aux`
+    bool overlap = true;           // hand inverse blocks to the other streams while the factorisation runs
     double last_ll = NAN, last_g[3] = {NAN, NAN, NAN}, last_quad = NAN, last_logdet = NAN;
     // profiling
     int prof = 0;
@@ -125,13 +131,53 @@ void drain_kernel_events(cugp_gp* g)
     g->kev_used = 0;
 }
 
-// Blocked right-looking Cholesky of A (lower), one stream, two launches per step:
+// Inverse quantities of block rows [a, b): T and U = T^T (diagonal-tile inverses, doubling inside the block,
+// bordering against the finished rows [0, a)) and the block's share of K^-1 = T^T T (when Kinv is wanted).
+// The block's own inverse is a chain of small launches; on its own stream `xs` (when given) it runs beside
+// the large products of the previous block instead of in front of this block's.
+int enqueue_inverse_block(cugp_gp* g, int a, int b, bool kinv, hipStream_t x, hipStream_t xs, hipEvent_t own_done)
+{
+    const int ld = g->npad, wb = b - a;
+    const size_t off = (size_t)a * TILE * ld + (size_t)a * TILE;
+    hipStream_t o = xs ? xs : x;
+    launch_trtri_diag(g->dA, ld, a, wb, g->d16, g->dT, g->dU, o);
+    for (int s = 1; s < wb; s *= 2) {
+        launch_trtri_level(g->dA + off, g->dT + off, g->dU + off, ld, wb, s, 1, o);
+        launch_trtri_level(g->dA + off, g->dT + off, g->dU + off, ld, wb, s, 2, o);
+    }
+    if (xs) HIPCHK(hipEventRecord(own_done, xs));
+    if (a > 0) launch_trtri_border(g->dA, g->dT, g->dU, ld, a, wb, 1, x);     // needs rows < a only
+    if (xs) HIPCHK(hipStreamWaitEvent(x, own_done, 0));
+    if (a > 0) launch_trtri_border(g->dA, g->dT, g->dU, ld, a, wb, 2, x);
+    if (kinv) launch_lauum(g->dU, g->dKinv, ld, a, wb, x);
+    return CUGP_OK;
+}
+
+// Blocked right-looking Cholesky of A (lower), two launches per step on the main stream:
 //   panel solve(k)  ->  [trailing update(k) + factorisation of diagonal block k+1] in ONE launch
 // (k_syrk_step: the latency-bound diagonal block runs inside the MFMA-bound trailing update).
-int enqueue_potrf(cugp_gp* g)
+// with_inverse: the factorisation's tail is a chain of small launches that leaves most of the chip idle,
+// while L^-1 and K^-1 can be built block row by block row as soon as the rows of L are final -- so every
+// `w` finished block rows are handed to a second, low-priority stream (fork by event) and the main stream
+// joins it at the end.  Each block's work is ordered on that stream, so results do not depend on timing.
+int fork_inverse_block(cugp_gp* g, int a, int b, int idx)
 {
+    HIPCHK(hipEventRecord(g->bev[idx], g->stream));
+    HIPCHK(hipStreamWaitEvent(g->aux, g->bev[idx], 0));
+    HIPCHK(hipStreamWaitEvent(g->aux2, g->bev[idx], 0));
+    return enqueue_inverse_block(g, a, b, true, g->aux, g->aux2, g->oev[idx]);
+}
+
+int enqueue_potrf(cugp_gp* g, bool with_inverse)
+{
+    int rc;
     hipStream_t m = g->stream;
     const int nt = g->nt, ld = g->npad;
+    // block rows per hand-over: about an eighth of the matrix (A/B runs at 12..64 tiles), or as tuned
+    int w = (with_inverse && g->overlap) ? g_tune[TUNE_PIPE_BLOCK] : 0;
+    if (w < 0) w = nt < 16 ? 2 : (nt + 4) / 8;
+    if (w >= nt) w = 0;
+    int nblk = 0, done = 0;                                 // blocks forked so far, block rows handed over
     HIPCHK(hipMemsetAsync(g->dtickets, 0, (size_t)nt * sizeof(unsigned), m));
     launch_potf2(g->dA, ld, 0, g->d16, g->d64, g->dlogdet, m);
     for (int kb = 0; kb + 1 < nt; kb++) {
@@ -145,10 +191,32 @@ int enqueue_potrf(cugp_gp* g)
             const double me = (double)(nt - kb - 1) * TILE;
             g->kev_flop += me * me * TILE;                  // lower triangle only: m^2 * nb (mul+add)
         }
+        const int b = kb + 2;                               // block rows < b are final (diagonal block kb+1 included)
+        if (w > 0 && b - done >= w && b < nt) {
+            if ((rc = fork_inverse_block(g, done, b, nblk))) return rc;
+            done = b;
+            nblk++;
+        }
     }
-    // inverses of all diagonal factor blocks at once (off the factorisation's critical path)
-    launch_trtri_diag(g->dA, ld, 0, nt, g->d16, g->dT, g->dU, m);
+    if (w > 0) {
+        if ((rc = fork_inverse_block(g, done, nt, nblk))) return rc;
+        HIPCHK(hipEventRecord(g->bev.back(), g->aux));
+        g->joined = false;
+    } else if (with_inverse) {
+        if ((rc = enqueue_inverse_block(g, 0, nt, true, m, nullptr, nullptr))) return rc;
+    } else {
+        // inverses of all diagonal factor blocks at once (off the factorisation's critical path)
+        launch_trtri_diag(g->dA, ld, 0, nt, g->d16, g->dT, g->dU, m);
+    }
     HIPCHK(hipGetLastError());
+    return CUGP_OK;
+}
+
+// main stream waits for the inverse blocks running on the second stream
+int join_inverse(cugp_gp* g)
+{
+    if (!g->joined) HIPCHK(hipStreamWaitEvent(g->stream, g->bev.back(), 0));
+    g->joined = true;
     return CUGP_OK;
 }
 
@@ -183,12 +251,11 @@ int enqueue_eval(cugp_gp* g, bool want_grad)
     if ((rc = phase_mark(g, 0))) return rc;
     launch_kbuild(g->dX, g->n, g->d, g->npad, h, g->dA, false, s);
     if ((rc = phase_mark(g, 1))) return rc;
-    if ((rc = enqueue_potrf(g))) return rc;
+    if ((rc = enqueue_potrf(g, want_grad))) return rc;      // + L^-1 and K^-1, block rows at a time beside it
     if ((rc = phase_mark(g, 2))) return rc;
     if (want_grad) {
-        if ((rc = enqueue_trtri(g))) return rc;
-        if ((rc = phase_mark(g, 3))) return rc;
-        launch_lauum(g->dU, g->dKinv, g->npad, g->nt, s);
+        if ((rc = join_inverse(g))) return rc;
+        if ((rc = phase_mark(g, 3))) return rc;              // "trtri" phase = what is left of the inverse blocks
         if ((rc = phase_mark(g, 4))) return rc;
         launch_trmv_lower(g->dT, g->npad, g->npad, g->dy, g->dz, s);        // z = L^-1 y
         launch_trmv_upper(g->dU, g->npad, g->npad, g->dz, g->dalpha, s);    // alpha = L^-T z
@@ -262,7 +329,15 @@ int cugp_create(int n, int d, int device, cugp_gp** out)
     g->nblocks_trace = trace_num_blocks(g->npad);
     *out = nullptr;
     hipError_t e = hipSetDevice(device);
+    // default priority everywhere: prioritised streams share few hardware queues, which serialises the
+    // experts of a BCM evaluated on one device
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->aux, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->aux2, hipStreamNonBlocking);
+    g->bev.assign((size_t)g->nt + 1, nullptr);
+    g->oev.assign((size_t)g->nt + 1, nullptr);
+    for (size_t i = 0; i < g->bev.size() && e == hipSuccess; i++) e = hipEventCreateWithFlags(&g->bev[i], hipEventDisableTiming);
+    for (size_t i = 0; i < g->oev.size() && e == hipSuccess; i++) e = hipEventCreateWithFlags(&g->oev[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipMalloc((void**)&g->dX, (size_t)n * d * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&g->dy, (size_t)g->npad * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&g->dz, (size_t)g->npad * sizeof(double));
@@ -290,6 +365,8 @@ int cugp_destroy(cugp_gp* g)
     if (!g) return CUGP_OK;
     (void)hipSetDevice(g->device);
     if (g->stream) (void)hipStreamSynchronize(g->stream);
+    if (g->aux) (void)hipStreamSynchronize(g->aux);
+    if (g->aux2) (void)hipStreamSynchronize(g->aux2);
     double* bufs[] = {g->dX, g->dy, g->dA, g->dT, g->dU, g->dKinv, g->dz, g->dalpha, g->dw, g->d16, g->dlogdet,
                       g->dpart, g->dout, g->d64};
     for (double* p : bufs)
@@ -299,8 +376,21 @@ int cugp_destroy(cugp_gp* g)
     for (int i = 0; i <= NPHASE; i++)
         if (g->pev[i]) (void)hipEventDestroy(g->pev[i]);
     for (hipEvent_t e : g->kev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : g->bev)
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : g->oev)
+        if (e) (void)hipEventDestroy(e);
+    if (g->aux) (void)hipStreamDestroy(g->aux);
+    if (g->aux2) (void)hipStreamDestroy(g->aux2);
     if (g->stream) (void)hipStreamDestroy(g->stream);
     delete g;
+    return CUGP_OK;
+}
+
+int cugp_set_overlap(cugp_gp* g, int enable)
+{
+    if (!g) return CUGP_ERR_INVALID;
+    g->overlap = enable != 0;
     return CUGP_OK;
 }
 
@@ -590,11 +680,8 @@ int la_handle(int n, const double* K, const double* y, int device, cugp_gp** out
 int la_factor_inverse(cugp_gp* g, bool inverse)
 {
     int rc;
-    if ((rc = enqueue_potrf(g))) return rc;
-    if (inverse) {
-        if ((rc = enqueue_trtri(g))) return rc;
-        launch_lauum(g->dU, g->dKinv, g->npad, g->nt, g->stream);
-    }
+    if ((rc = enqueue_potrf(g, inverse))) return rc;
+    if (inverse && (rc = join_inverse(g))) return rc;
     HIPCHK(hipStreamSynchronize(g->stream));
     g->factor_valid = true;
     g->inverse_valid = inverse;
@@ -630,7 +717,7 @@ static int la_solve(int n, const double* K, const double* y, double* x, double* 
     cugp_gp* g = nullptr;
     int rc = la_handle(n, K, y, device, &g);
     if (rc) return rc;
-    if (!(rc = enqueue_potrf(g)) && !(rc = enqueue_trtri(g))) {
+    if (!(rc = enqueue_potrf(g, false)) && !(rc = enqueue_trtri(g))) {
         launch_trmv_lower(g->dT, g->npad, g->npad, g->dy, g->dz, g->stream);
         launch_trmv_upper(g->dU, g->npad, g->npad, g->dz, g->dalpha, g->stream);
         launch_finalize(g->dz, g->npad, g->n, g->dlogdet, g->nt, nullptr, 0, scalars(g), g->dout, g->stream);
@@ -787,14 +874,15 @@ int cugp_bench_la(int op, int n, int device, int reps, double* ms)
     double best = 1e300;
     for (int r = 0; r < reps + 1 && e == hipSuccess && rc == CUGP_OK; r++) {
         launch_kbuild(g->dX, g->n, g->d, g->npad, scalars(g), g->dA, op == 4, g->stream);
-        if (op == 1 || op == 2) rc = enqueue_potrf(g);
+        if (op == 1 || op == 2) rc = enqueue_potrf(g, false);
         if (op == 2 && !rc) rc = enqueue_trtri(g);
         if (rc) break;
         e = hipEventRecord(e0, g->stream);
         if (op == 4) launch_test_gemm_nt(g->dA, g->dA, g->dKinv, g->npad, g->npad, g->npad, g->stream);   // uniform tiles
-        if (op == 0 || op == 3) rc = enqueue_potrf(g);
-        if ((op == 1 || op == 3) && !rc) rc = enqueue_trtri(g);
-        if ((op == 2 || op == 3) && !rc) launch_lauum(g->dU, g->dKinv, g->npad, g->nt, g->stream);
+        if (op == 0) rc = enqueue_potrf(g, false);
+        if (op == 1) rc = enqueue_trtri(g);
+        if (op == 2) launch_lauum(g->dU, g->dKinv, g->npad, 0, g->nt, g->stream);
+        if (op == 3 && !(rc = enqueue_potrf(g, true))) rc = join_inverse(g);   // as an evaluation runs them
         if (e == hipSuccess) e = hipEventRecord(e1, g->stream);
         if (e == hipSuccess) e = hipEventSynchronize(e1);
         float t = 0;

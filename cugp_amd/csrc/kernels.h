@@ -11,7 +11,9 @@ constexpr int TILE = 128;          // tile edge of every fp64 MFMA product and o
 enum { TUNE_LAUUM_WM2_MAX = 0,   // K^-1 product: use 64x64 tiles when there are at most this many 128-tiles
        TUNE_TRTRI_WM2_MAX = 1,   // inverse level: same rule
        TUNE_SYRK_REM_MAX = 2,    // trailing update: split the last partial round into 64x64 quarters when it has at most this many tiles
-       TUNE_COUNT = 3 };
+       TUNE_PIPE_BLOCK = 3,      // inverse rows (tiles) handed to the other streams at a time while the factorisation runs; 0 = after it, < 0 = about nt/8
+       TUNE_BORDER_CHUNK = 4,    // k tiles per launch of the bordering product (bounds workgroup duration); 0 = one launch
+       TUNE_COUNT = 5 };
 extern int g_tune[TUNE_COUNT];
 
 struct HyperScalars {              // exp(2*theta) evaluated on the host, as the reference does (covkernel.cpp:65-67)
@@ -40,7 +42,10 @@ void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* d6
 
 // ---- triangular inverse by recursive doubling (N7) and K^-1 = U U^T (N8) ----
 void launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, int s, int step, hipStream_t st);
-void launch_lauum(const double* U, double* Kinv, int ld, int nt, hipStream_t s);
+// rows [a, a+w) of the inverse from the finished leading block [0, a) and the block's own inverse (step 1, 2)
+void launch_trtri_border(const double* L, double* T, double* U, int ld, int a, int w, int step, hipStream_t st);
+// Kinv(lower tiles < a+w) (+)= contribution of inverse rows [a, a+w); a = 0, w = nt: the whole product
+void launch_lauum(const double* U, double* Kinv, int ld, int a, int w, hipStream_t s);
 
 // ---- prediction products ----
 // W[t][i] = sum_{k<=i} Ks[t][k] T[i][k]   (nt_pad x npad, row-major)

@@ -269,10 +269,12 @@ __device__ __forceinline__ void tri_index(int idx, int& ti, int& tj)
     tj = idx - r * (r + 1) / 2;
 }
 
-// ---- K^-1 (lower tiles, diagonal tiles complete) = U * U^T, U = L^-T upper ----
+// ---- K^-1 (lower tiles, diagonal tiles complete) = U * U^T, U = L^-T upper, taken one block of
+// inverse rows [a, a+w) at a time:  Kinv(ti,tj) (+)= sum_{k in [max(ti,a), a+w)} U[ti][k] U[tj][k]^T
+// for tj <= ti < a+w.  a = 0, w = nt is the whole product in one launch.
 template <int WM>
 __global__ __launch_bounds__(256, 2) void k_lauum(const double* __restrict__ U, double* __restrict__ Kinv, int ld,
-                                                  int nt)
+                                                  int a, int w)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SUB = 4 / WM, BT = 32 * WM;
@@ -280,23 +282,52 @@ __global__ __launch_bounds__(256, 2) void k_lauum(const double* __restrict__ U, 
     tri_index(blockIdx.x / (SUB * SUB), ti, tj);       // ascending ti = longest k ranges first
     const int sub = blockIdx.x % (SUB * SUB);
     const int si = (sub / SUB) * BT, sj = (sub % SUB) * BT;
+    double* C = Kinv + (size_t)(ti * TILE + si) * ld + tj * TILE + sj;
     d4 acc[WM][WM];
-    acc_zero(acc);
-    tile_nt<false>(U + (size_t)(ti * TILE + si) * ld, ld, U + (size_t)(tj * TILE + sj) * ld, ld, ti * TILE,
-                   nt * TILE, acc, smem);
-    tile_store(Kinv + (size_t)(ti * TILE + si) * ld + tj * TILE + sj, ld, acc, 1.0);
+    if (ti < a) tile_load<true>(C, ld, acc);           // rows of earlier blocks: add this block's share
+    else acc_zero(acc);
+    tile_nt<false>(U + (size_t)(ti * TILE + si) * ld, ld, U + (size_t)(tj * TILE + sj) * ld, ld,
+                   (ti < a ? a : ti) * TILE, (a + w) * TILE, acc, smem);
+    tile_store(C, ld, acc, 1.0);
 }
 
-// ---- recursive-doubling inverse, one level.  Blocks of s tiles: [A 0; C B]^-1 = [TA 0; -TB C TA, TB].
+// ---- triangular inverse.  [A 0; C B]^-1 = [TA 0; -TB C TA, TB] with A = tiles [.., b0), B = tiles [b0, ..):
 // step 1: Wt(tj in A, ti in B) = sum_{k in A, k >= tj} U[tj][k] * L[ti][k]   -> scratch in T's upper tiles
+//         (k tiles [kbeg, kend) of it; `accumulate` adds onto what earlier launches left there)
 // step 2: T(ti in B, tj in A) = -sum_{k in B, k <= ti} T[ti][k] * Wt[tj][k]   and U(tj,ti) = transpose
+template <int WM>
+__device__ __forceinline__ void trtri_tile(const double* __restrict__ L, double* __restrict__ T,
+                                           double* __restrict__ U, int ld, int tj, int ti, int step, int kbeg,
+                                           int kend, bool accumulate, int sub, char* smem)
+{
+    constexpr int SUB = 4 / WM;                          // output sub-tiles per 128-tile edge (1 or 2)
+    constexpr int BT = 32 * WM;
+    const int si = (sub / SUB) * BT, sj = (sub % SUB) * BT;     // offsets of my sub-tile inside the 128-tile
+    d4 acc[WM][WM];
+    if (step == 1) {
+        // Wt(tj, ti) rows in A's tile tj, columns in B's tile ti
+        double* W = T + (size_t)(tj * TILE + si) * ld + ti * TILE + sj;
+        if (accumulate) tile_load(W, ld, acc);
+        else acc_zero(acc);
+        tile_nt<false>(U + (size_t)(tj * TILE + si) * ld, ld, L + (size_t)(ti * TILE + sj) * ld, ld, kbeg * TILE,
+                       kend * TILE, acc, smem);
+        tile_store(W, ld, acc, 1.0);
+    } else {
+        acc_zero(acc);
+        tile_nt<true>(T + (size_t)(ti * TILE + si) * ld, ld, T + (size_t)(tj * TILE + sj) * ld, ld, kbeg * TILE,
+                      kend * TILE, acc, smem);
+        tile_store(T + (size_t)(ti * TILE + si) * ld + tj * TILE + sj, ld, acc, 1.0);
+        tile_store_t(U + (size_t)(tj * TILE + sj) * ld + ti * TILE + si, ld, acc, 1.0, smem);
+    }
+}
+
+// one level of recursive doubling: all pairs of s-tile blocks at once
 template <int WM>
 __global__ __launch_bounds__(256, 2) void k_trtri_level(const double* __restrict__ L, double* __restrict__ T,
                                                         double* __restrict__ U, int ld, int nt, int s, int step)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int SUB = 4 / WM;                          // output sub-tiles per 128-tile edge (1 or 2)
-    constexpr int BT = 32 * WM;
+    constexpr int SUB = 4 / WM;
     const int blk = blockIdx.x / (SUB * SUB), sub = blockIdx.x % (SUB * SUB);
     const int npairs = (nt + 2 * s - 1) / (2 * s);      // last one may have a short (or empty) B
     int p = blk / (s * s);
@@ -311,19 +342,27 @@ __global__ __launch_bounds__(256, 2) void k_trtri_level(const double* __restrict
     const int ja = (step == 1) ? rem / sb : rem % s;
     const int ib = (step == 1) ? rem % sb : sb - 1 - rem / s;
     const int tj = a0 + ja, ti = b0 + ib;
-    const int si = (sub / SUB) * BT, sj = (sub % SUB) * BT;     // offsets of my sub-tile inside the 128-tile
-    d4 acc[WM][WM];
-    acc_zero(acc);
+    trtri_tile<WM>(L, T, U, ld, tj, ti, step, step == 1 ? tj : b0, step == 1 ? b0 : ti + 1, false, sub, smem);
+}
+
+// bordering: rows B = [a, a+w) of the inverse from the finished leading block A = [0, a) and B's own
+// inverse (the same two steps with an unbalanced split; lets the inverse follow the factorisation
+// block row by block row).  Step 1 comes in launches over k chunks [c0, c1) of A, ascending, each adding
+// onto the last: workgroups stay short, so a waiting factorisation step finds free slots quickly.
+template <int WM>
+__global__ __launch_bounds__(256, 2) void k_trtri_border(const double* __restrict__ L, double* __restrict__ T,
+                                                         double* __restrict__ U, int ld, int a, int w, int step,
+                                                         int c0, int c1)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int SUB = 4 / WM;
+    const int blk = blockIdx.x / (SUB * SUB), sub = blockIdx.x % (SUB * SUB);
     if (step == 1) {
-        // Wt(tj, ti) rows in A's tile tj, columns in B's tile ti
-        tile_nt<false>(U + (size_t)(tj * TILE + si) * ld, ld, L + (size_t)(ti * TILE + sj) * ld, ld, tj * TILE,
-                       b0 * TILE, acc, smem);
-        tile_store(T + (size_t)(tj * TILE + si) * ld + ti * TILE + sj, ld, acc, 1.0);
+        const int tj = blk / w, ti = a + blk % w;                       // tj < c1
+        trtri_tile<WM>(L, T, U, ld, tj, ti, 1, tj > c0 ? tj : c0, c1, tj < c0, sub, smem);
     } else {
-        tile_nt<true>(T + (size_t)(ti * TILE + si) * ld, ld, T + (size_t)(tj * TILE + sj) * ld, ld, b0 * TILE,
-                      (ti + 1) * TILE, acc, smem);
-        tile_store(T + (size_t)(ti * TILE + si) * ld + tj * TILE + sj, ld, acc, 1.0);
-        tile_store_t(U + (size_t)(tj * TILE + sj) * ld + ti * TILE + si, ld, acc, 1.0, smem);
+        const int tj = blk % a, ti = a + w - 1 - blk / a;               // longest k range first
+        trtri_tile<WM>(L, T, U, ld, tj, ti, 2, a, ti + 1, false, sub, smem);
     }
 }
 
@@ -378,6 +417,7 @@ __global__ __launch_bounds__(256) void k_trsm_inv64(double* __restrict__ A, cons
                                                     int ld, int kb)
 {
     __shared__ double xbuf[4][4][64];
+    __builtin_amdgcn_s_setprio(3);                      // on the factorisation's serial chain (see k_syrk_step)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
     const int k0 = kb * TILE;
@@ -935,6 +975,9 @@ __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, in
     __shared__ double red[TILE];
     __shared__ unsigned s_ticket;
     if (blockIdx.x < NDIAGWG) {
+        // the factorisation's serial chain: win instruction issue over the product waves sharing the SIMD
+        // (this launch's own tiles and the inverse blocks running on the other streams)
+        __builtin_amdgcn_s_setprio(3);
         diag_update_wave(A, ld, kb, blockIdx.x * 4 + (threadIdx.x >> 6));
         // publish (cdna guide G16, counter form with write-through stores): every wave drains its sc1 stores,
         // workgroup barrier, then ONE lane draws the ticket (no agent release needed for sc1 stores)
@@ -958,6 +1001,7 @@ __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, in
     // written last by step kb (still in the 256 MiB Infinity Cache) are the first read by step kb+1.
     // Regular tiles: `nfull` of them as 128x128 workgroups; the rest (a partial last round that would
     // leave most of the chip idle for a whole tile time) as four 64x64 workgroups each.
+    __builtin_amdgcn_s_setprio(1);                      // ahead of the inverse-block products (priority 0)
     const int k0 = kb * TILE;
     const int x = blockIdx.x - NDIAGWG;
     if (x < nfull) {
@@ -1231,7 +1275,7 @@ __global__ __launch_bounds__(256) void k_predict_finish(const double* __restrict
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-int g_tune[TUNE_COUNT] = {768, 1200, 384};   // defaults chosen by interleaved A/B runs (tools/ab.py)
+int g_tune[TUNE_COUNT] = {768, 1200, 384, -1, 0};   // defaults chosen by interleaved A/B runs (tools/ab.py)
 
 static inline int tri_count(int n) { return n * (n + 1) / 2; }
 
@@ -1259,8 +1303,8 @@ static void set_big_lds()
     if (g_attr_done) return;
     (void)hipFuncSetAttribute((const void*)k_potf2, hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_LDS);
     (void)hipFuncSetAttribute((const void*)k_syrk_step, hipFuncAttributeMaxDynamicSharedMemorySize, STEP_LDS);
-    const void* gemm4[] = {(const void*)k_trtri_level<4>, (const void*)k_lauum<4>, (const void*)k_predict_gemm,
-                           (const void*)k_test_gemm};
+    const void* gemm4[] = {(const void*)k_trtri_level<4>, (const void*)k_trtri_border<4>, (const void*)k_lauum<4>,
+                           (const void*)k_predict_gemm, (const void*)k_test_gemm};
     for (const void* f : gemm4) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
     (void)hipFuncSetAttribute((const void*)k_trtri_diag, hipFuncAttributeMaxDynamicSharedMemorySize, TRTRI_LDS);
     g_attr_done = true;
@@ -1319,13 +1363,31 @@ void launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, i
         hipLaunchKernelGGL(k_trtri_level<4>, dim3(tiles), dim3(256), GEMM_LDS, st, L, T, U, ld, nt, s, step);
 }
 
-void launch_lauum(const double* U, double* Kinv, int ld, int nt, hipStream_t s)
+void launch_trtri_border(const double* L, double* T, double* U, int ld, int a, int w, int step, hipStream_t st)
+{
+    if (a <= 0 || w <= 0) return;
+    set_big_lds();
+    const int chunk = g_tune[TUNE_BORDER_CHUNK] > 0 ? g_tune[TUNE_BORDER_CHUNK] : a;
+    for (int c0 = 0; c0 < (step == 1 ? a : 1); c0 += chunk) {
+        const int c1 = c0 + chunk < a ? c0 + chunk : a;
+        const int tiles = (step == 1 ? c1 : a) * w;
+        if (tiles <= g_tune[TUNE_TRTRI_WM2_MAX])
+            hipLaunchKernelGGL(k_trtri_border<2>, dim3(tiles * 4), dim3(256), Geo<2>::LDS, st, L, T, U, ld, a, w, step,
+                               c0, c1);
+        else
+            hipLaunchKernelGGL(k_trtri_border<4>, dim3(tiles), dim3(256), GEMM_LDS, st, L, T, U, ld, a, w, step, c0,
+                               c1);
+    }
+}
+
+void launch_lauum(const double* U, double* Kinv, int ld, int a, int w, hipStream_t s)
 {
     set_big_lds();
-    if (tri_count(nt) <= g_tune[TUNE_LAUUM_WM2_MAX])
-        hipLaunchKernelGGL(k_lauum<2>, dim3(tri_count(nt) * 4), dim3(256), Geo<2>::LDS, s, U, Kinv, ld, nt);
+    const int tiles = tri_count(a + w);
+    if (tiles <= g_tune[TUNE_LAUUM_WM2_MAX])
+        hipLaunchKernelGGL(k_lauum<2>, dim3(tiles * 4), dim3(256), Geo<2>::LDS, s, U, Kinv, ld, a, w);
     else
-        hipLaunchKernelGGL(k_lauum<4>, dim3(tri_count(nt)), dim3(256), GEMM_LDS, s, U, Kinv, ld, nt);
+        hipLaunchKernelGGL(k_lauum<4>, dim3(tiles), dim3(256), GEMM_LDS, s, U, Kinv, ld, a, w);
 }
 
 void launch_predict_gemm(const double* Ks, const double* T, double* W, int ld, int ntt, int nt, hipStream_t s)

@@ -46,6 +46,11 @@ int cugp_device_count(int *count);
 int cugp_create(int n, int d, int device, cugp_gp **out);
 int cugp_destroy(cugp_gp *gp);
 int cugp_dims(const cugp_gp *gp, int *n, int *d, int *npad);
+/* A gradient evaluation builds L^-1 and K^-1 block row by block row on two further streams while the
+ * factorisation is still running (its tail leaves most of the chip idle).  On by default; cugp_bcm_create
+ * turns it off when several experts share the device.  No reference counterpart (the reference calls
+ * cusolverDnDpotrf, then inverts: cuda_scalingdist/cuda_gp.cu:647-708). */
+int cugp_set_overlap(cugp_gp *gp, int enable);
 
 /* ---- data: the X,y arguments of every Covsum method ; copy_training_data_to_GPU cuda_gp.cu:510-518 ---- */
 int cugp_set_data(cugp_gp *gp, const double *X, const double *y);

@@ -1,0 +1,25 @@
+"""Three LL+grad evaluations at one size, no profiling events: run under `rocprofv3 --kernel-trace` and feed the
+kernel trace to tools/timeline_report.py.   python3 tools/timeline_run.py <n> [pipe]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import cugp_amd.gp as gp                                  # noqa: E402
+from cugp_amd import capi                                 # noqa: E402
+from conftest import synth                                # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+if len(sys.argv) > 2:
+    capi.check(capi.lib().cugp_set_tuning(3, int(sys.argv[2])))
+X, y = synth(n)
+g = gp.Covsum(n, 10)
+g.set_data(X, y)
+hp = np.array([np.log(3.0), 0.0, np.log(0.1)])
+for it in range(3):
+    g.set_loghyperparam(hp + 1e-3 * it)
+    print(g.loglik_grad(), flush=True)
+g.close()
