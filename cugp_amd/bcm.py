@@ -51,6 +51,10 @@ class ShardedBCM:
             e = factory(X.shape[0], X.shape[1], device)
             e.set_data(X, y)
             self.local[k] = e
+        if len(self.local) > 1:                   # several experts on this GPU already overlap each other
+            for e in self.local.values():         # (as cugp_bcm_create does, csrc/bcm.cpp)
+                if hasattr(e, "set_overlap"):
+                    e.set_overlap(False)
         self.hp = np.zeros(3)
         if comm_device is None:
             comm_device = torch.device("cuda", device) if (world > 1 and dist.get_backend(group) == "nccl") \

@@ -45,6 +45,14 @@ int fail(int code, const char* what, hipError_t e = hipSuccess)
 
 constexpr int NPHASE = 6;
 constexpr int MAX_KEV = 4096;   // per-launch event pairs kept between resets
+constexpr int PROF_STRIDE = 8;  // profiling level 2 times every 8th trailing-update launch, rotating
+
+// One hardware queue per stream up to 16 (the runtime default is 4): the experts of a BCM on one device each
+// drive their own stream, and 16 experts on 4 queues serialise (5.8 ms vs 4.6 ms per evaluation of 16 x 1500
+// rows).  Only a default: an existing setting wins, and it has no effect once the HIP runtime is initialised.
+struct QueueDefault {
+    QueueDefault() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+} g_queue_default;
 
 }  // namespace
 
@@ -75,6 +83,7 @@ struct cugp_gp {
     bool pev_valid = false;
     std::vector<hipEvent_t> kev;   // start/stop pairs around trailing updates
     int kev_used = 0;
+    unsigned eval_seq = 0;         // factorisations enqueued so far (rotates the launches that get timed)
     double kev_flop = 0, kev_ms_done = 0;
     long long kev_launches_done = 0;
     double kev_flop_done = 0;
@@ -160,6 +169,8 @@ int enqueue_inverse_block(cugp_gp* g, int a, int b, bool kinv, hipStream_t x, hi
 // while L^-1 and K^-1 can be built block row by block row as soon as the rows of L are final -- so every
 // `w` finished block rows are handed to a second, low-priority stream (fork by event) and the main stream
 // joins it at the end.  Each block's work is ordered on that stream, so results do not depend on timing.
+int phase_mark(cugp_gp* g, int i);
+
 int fork_inverse_block(cugp_gp* g, int a, int b, int idx)
 {
     HIPCHK(hipEventRecord(g->bev[idx], g->stream));
@@ -168,7 +179,7 @@ int fork_inverse_block(cugp_gp* g, int a, int b, int idx)
     return enqueue_inverse_block(g, a, b, true, g->aux, g->aux2, g->oev[idx]);
 }
 
-int enqueue_potrf(cugp_gp* g, bool with_inverse)
+int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false)
 {
     int rc;
     hipStream_t m = g->stream;
@@ -178,11 +189,14 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse)
     if (w < 0) w = nt < 16 ? 2 : (nt + 4) / 8;
     if (w >= nt) w = 0;
     int nblk = 0, done = 0;                                 // blocks forked so far, block rows handed over
+    g->eval_seq++;
     HIPCHK(hipMemsetAsync(g->dtickets, 0, (size_t)nt * sizeof(unsigned), m));
     launch_potf2(g->dA, ld, 0, g->d16, g->d64, g->dlogdet, m);
     for (int kb = 0; kb + 1 < nt; kb++) {
         launch_trsm_inv64(g->dA, g->d64, ld, kb, nt, m);
-        const bool ev = g->prof >= 2 && g->kev_used + 2 <= (int)g->kev.size();
+        // level 2 times a rotating eighth of the launches (every step is sampled once in 8 evaluations):
+        // an event pair around every launch costs several percent of the evaluation
+        const bool ev = g->prof >= 2 && (kb + g->eval_seq) % PROF_STRIDE == 0 && g->kev_used + 2 <= (int)g->kev.size();
         if (ev) HIPCHK(hipEventRecord(g->kev[g->kev_used], m));
         launch_syrk_step(g->dA, ld, kb, nt, g->d16, g->d64, g->dlogdet, g->dtickets, m);
         if (ev) {
@@ -198,6 +212,7 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse)
             nblk++;
         }
     }
+    if (mark && (rc = phase_mark(g, 2))) return rc;         // end of the factorisation on the main stream
     if (w > 0) {
         if ((rc = fork_inverse_block(g, done, nt, nblk))) return rc;
         HIPCHK(hipEventRecord(g->bev.back(), g->aux));
@@ -251,8 +266,7 @@ int enqueue_eval(cugp_gp* g, bool want_grad)
     if ((rc = phase_mark(g, 0))) return rc;
     launch_kbuild(g->dX, g->n, g->d, g->npad, h, g->dA, false, s);
     if ((rc = phase_mark(g, 1))) return rc;
-    if ((rc = enqueue_potrf(g, want_grad))) return rc;      // + L^-1 and K^-1, block rows at a time beside it
-    if ((rc = phase_mark(g, 2))) return rc;
+    if ((rc = enqueue_potrf(g, want_grad, true))) return rc;   // + L^-1 and K^-1, block rows at a time beside it
     if (want_grad) {
         if ((rc = join_inverse(g))) return rc;
         if ((rc = phase_mark(g, 3))) return rc;              // "trtri" phase = what is left of the inverse blocks

@@ -177,7 +177,13 @@ class Covsum:
     def set_profiling(self, level):
         check(capi.lib().cugp_set_profiling(self._h, int(level)))
 
+    def set_overlap(self, enable):
+        """Inverse blocks on further streams while the factorisation runs (default on; cugp_set_overlap)."""
+        check(capi.lib().cugp_set_overlap(self._h, 1 if enable else 0))
+
     def phase_ms(self):
+        """Main-stream phases of the last evaluation.  With the overlap on, "potrf" includes the inverse blocks
+        running beside it and "trtri" is what was left of them when the factorisation ended ("lauum" ~ 0)."""
         ms = np.empty(6)
         check(capi.lib().cugp_get_phase_ms(self._h, ptr(ms)))
         return dict(zip(("kbuild", "potrf", "trtri", "lauum", "tail", "total"), ms.tolist()))
