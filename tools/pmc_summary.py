@@ -10,12 +10,14 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out")
-KERNELS = ("k_syrk_step", "k_lauum", "k_trtri_level", "k_build", "k_trace", "k_potf2", "k_trsm_inv64")
+KERNELS = ("k_syrk_step", "k_lauum", "k_trtri_level", "k_trtri_border", "k_trtri_diag", "k_build", "k_trace", "k_potf2",
+           "k_trsm_inv64")
 
 
 def load(tag):
     f = glob.glob(os.path.join(src, "pmc_%s" % tag, "*", "*counter_collection.csv"))
-    return list(csv.DictReader(open(f[0]))) if f else []
+    f.sort(key=os.path.getmtime)                       # gpurun_out keeps earlier runs: take the newest
+    return list(csv.DictReader(open(f[-1]))) if f else []
 
 
 def short(name):
