@@ -45,6 +45,7 @@ int fail(int code, const char* what, hipError_t e = hipSuccess)
 
 constexpr int NPHASE = 6;
 constexpr int MAX_KEV = 4096;   // per-launch event pairs kept between resets
+constexpr int GRAPH_MAX_TILES = 24;   // evaluations up to 3072 rows are replayed as captured graphs
 constexpr int PROF_STRIDE = 8;  // profiling level 2 times every 8th trailing-update launch, rotating
 
 // One hardware queue per stream up to 16 (the runtime default is 4): the experts of a BCM on one device each
@@ -76,6 +77,12 @@ struct cugp_gp {
     bool pending = false, pending_grad = false;
     bool joined = true;            // no inverse blocks outstanding on `aux`
     bool overlap = true;           // hand inverse blocks to the other streams while the factorisation runs
+    // a single-stream evaluation is captured once as a HIP graph and replayed: one launch call instead of
+    // ~60 (1500 rows) -- with 16 experts on a GPU the host's launch rate was the bound, not the device
+    HyperScalars* dhs = nullptr;   // device copy of exp(2*theta): what the kernels of a captured evaluation read
+    HyperScalars* hhs = nullptr;   // pinned staging for it (refreshed by a copy node at the head of the graph)
+    hipGraphExec_t gexec[2] = {nullptr, nullptr};   // [0] log-likelihood only, [1] with gradient
+    unsigned gepoch[2] = {0, 0};   // g_cfg_epoch the graph was captured under
     double last_ll = NAN, last_g[3] = {NAN, NAN, NAN}, last_quad = NAN, last_logdet = NAN;
     // profiling
     int prof = 0;
@@ -140,6 +147,17 @@ void drain_kernel_events(cugp_gp* g)
     g->kev_used = 0;
 }
 
+unsigned g_cfg_epoch = 1;          // bumped by cugp_set_tuning: captured graphs carry launch shapes
+
+// block rows per hand-over to the other streams: about an eighth of the matrix (A/B runs at 12..64 tiles),
+// or as tuned; 0 = no hand-over (everything on the main stream after the factorisation)
+int pipe_block(const cugp_gp* g, bool with_inverse)
+{
+    int w = (with_inverse && g->overlap) ? g_tune[TUNE_PIPE_BLOCK] : 0;
+    if (w < 0) w = g->nt < 16 ? 2 : (g->nt + 4) / 8;
+    return w >= g->nt ? 0 : w;
+}
+
 // Inverse quantities of block rows [a, b): T and U = T^T (diagonal-tile inverses, doubling inside the block,
 // bordering against the finished rows [0, a)) and the block's share of K^-1 = T^T T (when Kinv is wanted).
 // The block's own inverse is a chain of small launches; on its own stream `xs` (when given) it runs beside
@@ -170,6 +188,7 @@ int enqueue_inverse_block(cugp_gp* g, int a, int b, bool kinv, hipStream_t x, hi
 // `w` finished block rows are handed to a second, low-priority stream (fork by event) and the main stream
 // joins it at the end.  Each block's work is ordered on that stream, so results do not depend on timing.
 int phase_mark(cugp_gp* g, int i);
+int fetch_eval(cugp_gp* g);
 
 int fork_inverse_block(cugp_gp* g, int a, int b, int idx)
 {
@@ -184,10 +203,7 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false)
     int rc;
     hipStream_t m = g->stream;
     const int nt = g->nt, ld = g->npad;
-    // block rows per hand-over: about an eighth of the matrix (A/B runs at 12..64 tiles), or as tuned
-    int w = (with_inverse && g->overlap) ? g_tune[TUNE_PIPE_BLOCK] : 0;
-    if (w < 0) w = nt < 16 ? 2 : (nt + 4) / 8;
-    if (w >= nt) w = 0;
+    const int w = pipe_block(g, with_inverse);
     int nblk = 0, done = 0;                                 // blocks forked so far, block rows handed over
     g->eval_seq++;
     HIPCHK(hipMemsetAsync(g->dtickets, 0, (size_t)nt * sizeof(unsigned), m));
@@ -251,20 +267,16 @@ int phase_mark(cugp_gp* g, int i)
     return CUGP_OK;
 }
 
-// K build + factorisation (+ inverse quantities, traces when want_grad); results land in dout
-int enqueue_eval(cugp_gp* g, bool want_grad)
+// K build + factorisation (+ inverse quantities, traces when want_grad); results land in dout.
+// hd: the kernels read the hyper-scalars from device memory (a copy node refreshes it) -- the captured form.
+int record_eval(cugp_gp* g, bool want_grad, const HyperScalars* hd)
 {
     int rc;
-    if (!g->have_data) return fail(CUGP_ERR_INVALID, "no training data set (cugp_set_data)");
-    if ((rc = use_device(g))) return rc;
-    if ((rc = ensure_factor_bufs(g))) return rc;
-    if (want_grad && (rc = ensure_inverse_bufs(g))) return rc;
     const HyperScalars h = scalars(g);
     hipStream_t s = g->stream;
-    g->factor_valid = g->inverse_valid = false;
-
+    if (hd) HIPCHK(hipMemcpyAsync(g->dhs, g->hhs, sizeof(HyperScalars), hipMemcpyHostToDevice, s));
     if ((rc = phase_mark(g, 0))) return rc;
-    launch_kbuild(g->dX, g->n, g->d, g->npad, h, g->dA, false, s);
+    launch_kbuild(g->dX, g->n, g->d, g->npad, h, g->dA, false, s, hd);
     if ((rc = phase_mark(g, 1))) return rc;
     if ((rc = enqueue_potrf(g, want_grad, true))) return rc;   // + L^-1 and K^-1, block rows at a time beside it
     if (want_grad) {
@@ -273,18 +285,60 @@ int enqueue_eval(cugp_gp* g, bool want_grad)
         if ((rc = phase_mark(g, 4))) return rc;
         launch_trmv_lower(g->dT, g->npad, g->npad, g->dy, g->dz, s);        // z = L^-1 y
         launch_trmv_upper(g->dU, g->npad, g->npad, g->dz, g->dalpha, s);    // alpha = L^-T z
-        launch_trace(g->dX, g->n, g->d, g->npad, h, g->dKinv, g->dalpha, g->dpart, s);
-        launch_finalize(g->dz, g->npad, g->n, g->dlogdet, g->nt, g->dpart, g->nblocks_trace, h, g->dout, s);
+        launch_trace(g->dX, g->n, g->d, g->npad, h, g->dKinv, g->dalpha, g->dpart, s, hd);
+        launch_finalize(g->dz, g->npad, g->n, g->dlogdet, g->nt, g->dpart, g->nblocks_trace, h, g->dout, s, hd);
     } else {
         if ((rc = phase_mark(g, 3))) return rc;
         if ((rc = phase_mark(g, 4))) return rc;
         HIPCHK(hipMemcpyAsync(g->dw, g->dy, (size_t)g->npad * sizeof(double), hipMemcpyDeviceToDevice, s));
         launch_trsv_lower(g->dA, g->dT, g->npad, g->nt, g->dw, g->dz, s);   // L z = y
-        launch_finalize(g->dz, g->npad, g->n, g->dlogdet, g->nt, nullptr, 0, h, g->dout, s);
+        launch_finalize(g->dz, g->npad, g->n, g->dlogdet, g->nt, nullptr, 0, h, g->dout, s, hd);
     }
     if ((rc = phase_mark(g, 5))) return rc;
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(g->hout, g->dout, 6 * sizeof(double), hipMemcpyDeviceToHost, s));
+    return CUGP_OK;
+}
+
+int enqueue_eval(cugp_gp* g, bool want_grad)
+{
+    int rc;
+    if (!g->have_data) return fail(CUGP_ERR_INVALID, "no training data set (cugp_set_data)");
+    if ((rc = fetch_eval(g))) return rc;                      // one evaluation in flight per handle
+    if ((rc = use_device(g))) return rc;
+    if ((rc = ensure_factor_bufs(g))) return rc;
+    if (want_grad && (rc = ensure_inverse_bufs(g))) return rc;
+    g->factor_valid = g->inverse_valid = false;
+
+    // Replay a captured graph when the evaluation is a single-stream sequence (no hand-over to the other
+    // streams) and nothing is being timed; otherwise enqueue the launches one by one.
+    // (measured: 16 x 1500 rows 4.7 -> 4.1 ms, 2 x 1500 rows 1.25 -> 1.18 ms; nothing to gain above ~3000 rows)
+    const bool graph = g_tune[TUNE_GRAPHS] != 0 && g->prof == 0 && g->nt <= GRAPH_MAX_TILES &&
+                       pipe_block(g, want_grad) == 0;
+    if (!graph) {
+        if ((rc = record_eval(g, want_grad, nullptr))) return rc;
+    } else {
+        const int gi = want_grad ? 1 : 0;
+        *g->hhs = scalars(g);
+        if (!g->gexec[gi] || g->gepoch[gi] != g_cfg_epoch) {
+            if (g->gexec[gi]) (void)hipGraphExecDestroy(g->gexec[gi]);
+            g->gexec[gi] = nullptr;
+            prepare_kernels();
+            hipGraph_t graph_obj = nullptr;
+            HIPCHK(hipStreamBeginCapture(g->stream, hipStreamCaptureModeThreadLocal));
+            rc = record_eval(g, want_grad, g->dhs);
+            const hipError_t e = hipStreamEndCapture(g->stream, &graph_obj);   // always leave capture mode
+            if (rc || e != hipSuccess) {
+                if (graph_obj) (void)hipGraphDestroy(graph_obj);
+                return rc ? rc : fail(CUGP_ERR_DEVICE, "hipStreamEndCapture", e);
+            }
+            const hipError_t ei = hipGraphInstantiate(&g->gexec[gi], graph_obj, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(graph_obj);
+            if (ei != hipSuccess) { g->gexec[gi] = nullptr; return fail(CUGP_ERR_DEVICE, "hipGraphInstantiate", ei); }
+            g->gepoch[gi] = g_cfg_epoch;
+        }
+        HIPCHK(hipGraphLaunch(g->gexec[gi], g->stream));
+    }
     g->pending = true;
     g->pending_grad = want_grad;
     g->pev_valid = g->prof >= 1;
@@ -364,6 +418,8 @@ int cugp_create(int n, int d, int device, cugp_gp** out)
     if (e == hipSuccess) e = hipMalloc((void**)&g->dout, 8 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&g->dtickets, (size_t)g->nt * sizeof(unsigned));
     if (e == hipSuccess) e = hipHostMalloc((void**)&g->hout, 8 * sizeof(double), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipHostMalloc((void**)&g->hhs, sizeof(HyperScalars), hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void**)&g->dhs, sizeof(HyperScalars));
     for (int i = 0; i <= NPHASE && e == hipSuccess; i++) e = hipEventCreate(&g->pev[i]);
     if (e != hipSuccess) {
         int code = fail(e == hipErrorOutOfMemory ? CUGP_ERR_NOMEM : CUGP_ERR_DEVICE, "cugp_create", e);
@@ -387,6 +443,10 @@ int cugp_destroy(cugp_gp* g)
         if (p) (void)hipFree(p);
     if (g->dtickets) (void)hipFree(g->dtickets);
     if (g->hout) (void)hipHostFree(g->hout);
+    if (g->hhs) (void)hipHostFree(g->hhs);
+    if (g->dhs) (void)hipFree(g->dhs);
+    for (hipGraphExec_t x : g->gexec)
+        if (x) (void)hipGraphExecDestroy(x);
     for (int i = 0; i <= NPHASE; i++)
         if (g->pev[i]) (void)hipEventDestroy(g->pev[i]);
     for (hipEvent_t e : g->kev) (void)hipEventDestroy(e);
@@ -405,7 +465,7 @@ int cugp_set_overlap(cugp_gp* g, int enable)
 {
     if (!g) return CUGP_ERR_INVALID;
     g->overlap = enable != 0;
-    return CUGP_OK;
+    return CUGP_OK;                                          // (a captured graph is only used without hand-over)
 }
 
 int cugp_dims(const cugp_gp* g, int* n, int* d, int* npad)
@@ -842,6 +902,7 @@ int cugp_rprop_solve(cugp_gp* g, int iters, double* trace, int trace_cap, int* n
 int cugp_set_tuning(int key, int value)
 {
     if (key < 0 || key >= TUNE_COUNT) return CUGP_ERR_INVALID;
+    if (g_tune[key] != value && key != TUNE_GRAPHS) g_cfg_epoch++;   // launch shapes changed: recapture graphs
     g_tune[key] = value;
     return CUGP_OK;
 }

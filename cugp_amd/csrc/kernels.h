@@ -13,7 +13,8 @@ enum { TUNE_LAUUM_WM2_MAX = 0,   // K^-1 product: use 64x64 tiles when there are
        TUNE_SYRK_REM_MAX = 2,    // trailing update: split the last partial round into 64x64 quarters when it has at most this many tiles
        TUNE_PIPE_BLOCK = 3,      // inverse rows (tiles) handed to the other streams at a time while the factorisation runs; 0 = after it, < 0 = about nt/8
        TUNE_BORDER_CHUNK = 4,    // k tiles per launch of the bordering product (bounds workgroup duration); 0 = one launch
-       TUNE_COUNT = 5 };
+       TUNE_GRAPHS = 5,          // replay single-stream evaluations as a captured HIP graph (1) or launch by launch (0)
+       TUNE_COUNT = 6 };
 extern int g_tune[TUNE_COUNT];
 
 struct HyperScalars {              // exp(2*theta) evaluated on the host, as the reference does (covkernel.cpp:65-67)
@@ -22,8 +23,9 @@ struct HyperScalars {              // exp(2*theta) evaluated on the host, as the
 
 // ---- SE covariance (N1) ----
 // lower 64x64 tiles of K (+ mirror when `full`), padding rows/cols >= n set to identity
+// hd (optional, also below): read the hyper-scalars from device memory instead of the argument
 void launch_kbuild(const double* X, int n, int d, int npad, HyperScalars h, double* K, bool full,
-                   hipStream_t s);
+                   hipStream_t s, const HyperScalars* hd = nullptr);
 // S[i][j] = |x_i - x_j|^2 / c, zero diagonal, full symmetric (N2, covkernel.cpp:130-157)
 void launch_sqdist(const double* X, int n, int d, int npad, double c, double* S, hipStream_t s);
 // Ks[t][i] = sf2 * exp(-0.5*|x_i - xt_t|^2 / l^2), row-major nt_pad x npad (pad = 0)   (N12)
@@ -61,10 +63,12 @@ void launch_trsv_lower(const double* A, const double* T, int ld, int nt, const d
 // gradient traces (N10+N11 fused): partial sums per block into part[3*nblocks]
 int trace_num_blocks(int npad);
 void launch_trace(const double* X, int n, int d, int npad, HyperScalars h, const double* Kinv,
-                  const double* alpha, double* part, hipStream_t s);
+                  const double* alpha, double* part, hipStream_t s, const HyperScalars* hd = nullptr);
 // out[0..3] = LL, g0, g1, g2  (LL only when part == nullptr)
 void launch_finalize(const double* z, int npad, int n, const double* logdet_part, int nt, const double* part,
-                     int nblocks, HyperScalars h, double* out, hipStream_t s);
+                     int nblocks, HyperScalars h, double* out, hipStream_t s, const HyperScalars* hd = nullptr);
+// one-time function attributes (dynamic LDS sizes); the launchers do it lazily, a stream capture must not
+void prepare_kernels();
 
 // test hook: C[m x n] = A[m x k] * B[n x k]^T on the MFMA tile path (all multiples of 128 / 16)
 void launch_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, int k, hipStream_t s);

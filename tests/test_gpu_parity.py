@@ -268,6 +268,39 @@ def test_bcm_golden(gp_mod, si128, golden_si128):
     assert np.allclose(v, u["pred_var"], rtol=1e-8, atol=1e-8)
 
 
+def test_graph_replay_matches_launch_by_launch(gp_mod, si128):
+    """Single-stream evaluations are replayed from a captured HIP graph (tuning key 5): same numbers as
+    launch by launch, also after the hyper-parameters and the data change under the captured graph."""
+    from cugp_amd import capi
+    X, y = si128
+    res = {}
+    for mode in (1, 0):
+        capi.check(capi.lib().cugp_set_tuning(5, mode))
+        try:
+            b = gp_mod.BCM.split(X, y, 4)
+            out = []
+            for hp in (HP_BCM, HP_DENSE, HP_BCM):
+                b.set_BCM_log_hyperparam(np.array(hp))
+                ll, g, per = b.loglik_grad()
+                out.append(np.concatenate([[ll], g, per]))
+            b.set_expert_data(0, X[32:64], y[32:64])           # same buffers, new contents
+            ll, g, per = b.loglik_grad()
+            out.append(np.concatenate([[ll], g, per]))
+            b.close()
+            one = gp_mod.Covsum(X.shape[0], X.shape[1])        # one tile: no hand-over, so it is replayed too
+            one.set_data(X, y)
+            for hp in (HP_BCM, HP_DENSE):
+                one.set_loghyperparam(np.array(hp))
+                out.append(np.array([one.compute_loglikelihood()]))      # the log-likelihood-only graph
+                ll, g = one.loglik_grad()
+                out.append(np.concatenate([[ll], g]))
+            one.close()
+            res[mode] = np.concatenate(out)
+        finally:
+            capi.check(capi.lib().cugp_set_tuning(5, 1))
+    assert np.array_equal(res[0], res[1])
+
+
 def test_bcm_cg_golden(gp_mod, si128, golden_si128):
     X, y = si128
     c = golden_si128["bcm"]["cg"]
