@@ -76,6 +76,9 @@ def main():
                          "(e.g. --experts-total 16 --rows 1500 = the si24000 16-shard shape); value = BCM objective "
                          "evaluations/s (all experts + all-reduce per evaluation)")
     ap.add_argument("--cpu-sample", type=int, default=2048, help="rows for the CPU baseline (0 = skip)")
+    ap.add_argument("--overlap", type=int, default=1, help="0: build the inverse after the factorisation on one stream "
+                    "(every kernel has the chip to itself: the per-kernel roofline of the whole run is the isolated one "
+                    "and no extra pass is made)")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
@@ -115,6 +118,8 @@ def main():
     bcm = ShardedBCM(experts, rank=rank, world=world, device=local_rank)
     for e in bcm.local.values():
         e.set_profiling(2)
+        if not args.overlap:
+            e.set_overlap(False)
 
     def step(i):
         bcm.set_loghyper(HP0 + 1e-3 * ((i % 7) - 3))          # fresh hyper-parameters: nothing is cached
@@ -150,7 +155,7 @@ def main():
     # run beside the factorisation on other streams, so a trailing-update launch shares the CUs and its duration
     # is not a statement about the kernel alone; eight more evaluations with the overlap off give that number.
     iso = iso_ph = None
-    if rank == 0 and len(bcm.local) == 1:
+    if rank == 0 and len(bcm.local) == 1 and args.overlap:
         first.set_overlap(False)
         first.kernel_stats(reset=True)
         for i in range(8):                        # level-2 profiling times every 8th launch, rotating
@@ -171,7 +176,7 @@ def main():
             "config": {"workload": ("bcm_%dx%d_D%d" % (K, args.n, args.d)) if strong
                        else "gp_loglik_grad_N%d_D%d" % (args.n, args.d), "experts": K,
                        "experts_per_gpu": (K + world - 1) // world if strong else args.experts_per_gpu,
-                       "sharding": "bcm-experts-per-gpu",
+                       "sharding": "bcm-experts-per-gpu", "overlap": bool(args.overlap) and len(bcm.local) == 1,
                        "hp": HP0.tolist()},
             "cholesky_gflops": (npad ** 3 / 3.0) / ((iso_ph or ph)["potrf"] * 1e-3) / 1e9,   # factorisation alone (overlap off)
             "eval_tflops_n3": (float(args.n) ** 3) * (K if strong else world * args.experts_per_gpu) / world
