@@ -172,10 +172,14 @@ int enqueue_inverse_block(cugp_gp* g, int a, int b, bool kinv, hipStream_t x, hi
         launch_trtri_level(g->dA + off, g->dT + off, g->dU + off, ld, wb, s, 1, o);
         launch_trtri_level(g->dA + off, g->dT + off, g->dU + off, ld, wb, s, 2, o);
     }
-    if (xs) HIPCHK(hipEventRecord(own_done, xs));
-    if (a > 0) launch_trtri_border(g->dA, g->dT, g->dU, ld, a, wb, 1, x);     // needs rows < a only
-    if (xs) HIPCHK(hipStreamWaitEvent(x, own_done, 0));
-    if (a > 0) launch_trtri_border(g->dA, g->dT, g->dU, ld, a, wb, 2, x);
+    if (xs) {
+        HIPCHK(hipEventRecord(own_done, xs));
+        HIPCHK(hipStreamWaitEvent(x, own_done, 0));
+    }
+    // rows [a, b): their Wt was accumulated chunk by chunk while the earlier blocks became final
+    if (a > 0) launch_trtri_border2(g->dA, g->dT, g->dU, ld, a, wb, x);
+    // ... and these rows, now final, go into the Wt of every row below them
+    if (b < g->nt) launch_trtri_border1(g->dA, g->dT, g->dU, ld, b, g->nt - b, a, b, x);
     if (kinv) launch_lauum(g->dU, g->dKinv, ld, a, wb, x);
     return CUGP_OK;
 }
@@ -210,6 +214,13 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false)
     launch_potf2(g->dA, ld, 0, g->d16, g->d64, g->dlogdet, m);
     for (int kb = 0; kb + 1 < nt; kb++) {
         launch_trsm_inv64(g->dA, g->d64, ld, kb, nt, m);
+        // block rows < kb+1 of L are final, and so are the columns <= kb of every row below them
+        const int b = kb + 1;
+        if (w > 0 && b - done >= w) {
+            if ((rc = fork_inverse_block(g, done, b, nblk))) return rc;
+            done = b;
+            nblk++;
+        }
         // level 2 times a rotating eighth of the launches (every step is sampled once in 8 evaluations):
         // an event pair around every launch costs several percent of the evaluation
         const bool ev = g->prof >= 2 && (kb + g->eval_seq) % PROF_STRIDE == 0 && g->kev_used + 2 <= (int)g->kev.size();
@@ -220,12 +231,6 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false)
             g->kev_used += 2;
             const double me = (double)(nt - kb - 1) * TILE;
             g->kev_flop += me * me * TILE;                  // lower triangle only: m^2 * nb (mul+add)
-        }
-        const int b = kb + 2;                               // block rows < b are final (diagonal block kb+1 included)
-        if (w > 0 && b - done >= w && b < nt) {
-            if ((rc = fork_inverse_block(g, done, b, nblk))) return rc;
-            done = b;
-            nblk++;
         }
     }
     if (mark && (rc = phase_mark(g, 2))) return rc;         // end of the factorisation on the main stream

@@ -348,7 +348,8 @@ __global__ __launch_bounds__(256, 2) void k_trtri_level(const double* __restrict
 // bordering: rows B = [a, a+w) of the inverse from the finished leading block A = [0, a) and B's own
 // inverse (the same two steps with an unbalanced split; lets the inverse follow the factorisation
 // block row by block row).  Step 1 comes in launches over k chunks [c0, c1) of A, ascending, each adding
-// onto the last: workgroups stay short, so a waiting factorisation step finds free slots quickly.
+// onto the last; the host issues chunk [c0, c1) for ALL rows below it as soon as those inverse rows are
+// final (uniform K, and most of the work is done before the rows' own turn comes).
 template <int WM>
 __global__ __launch_bounds__(256, 2) void k_trtri_border(const double* __restrict__ L, double* __restrict__ T,
                                                          double* __restrict__ U, int ld, int a, int w, int step,
@@ -1283,7 +1284,7 @@ __global__ __launch_bounds__(256) void k_predict_finish(const double* __restrict
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-int g_tune[TUNE_COUNT] = {768, 1200, 384, -1, 0, 1};   // defaults chosen by interleaved A/B runs (tools/ab.py)
+int g_tune[TUNE_COUNT] = {768, 1200, 384, -1, 511, 1};   // defaults chosen by interleaved A/B runs (tools/ab.py)
 
 static inline int tri_count(int n) { return n * (n + 1) / 2; }
 
@@ -1375,21 +1376,31 @@ void launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, i
         hipLaunchKernelGGL(k_trtri_level<4>, dim3(tiles), dim3(256), GEMM_LDS, st, L, T, U, ld, nt, s, step);
 }
 
-void launch_trtri_border(const double* L, double* T, double* U, int ld, int a, int w, int step, hipStream_t st)
+// step 1 of the bordering, spread over time: add the k tiles [c0, c1) (a block of inverse rows that just
+// became final) to Wt(tj < c1, ti in [ra, ra+rw)) for ALL rows below the block
+void launch_trtri_border1(const double* L, double* T, double* U, int ld, int ra, int rw, int c0, int c1,
+                          hipStream_t st)
 {
-    if (a <= 0 || w <= 0) return;
+    const int tiles = c1 * rw;
+    if (tiles <= 0) return;
     set_big_lds();
-    const int chunk = g_tune[TUNE_BORDER_CHUNK] > 0 ? g_tune[TUNE_BORDER_CHUNK] : a;
-    for (int c0 = 0; c0 < (step == 1 ? a : 1); c0 += chunk) {
-        const int c1 = c0 + chunk < a ? c0 + chunk : a;
-        const int tiles = (step == 1 ? c1 : a) * w;
-        if (tiles <= g_tune[TUNE_TRTRI_WM2_MAX])
-            hipLaunchKernelGGL(k_trtri_border<2>, dim3(tiles * 4), dim3(256), Geo<2>::LDS, st, L, T, U, ld, a, w, step,
-                               c0, c1);
-        else
-            hipLaunchKernelGGL(k_trtri_border<4>, dim3(tiles), dim3(256), GEMM_LDS, st, L, T, U, ld, a, w, step, c0,
-                               c1);
-    }
+    if (tiles <= g_tune[TUNE_BORDER_WM2_MAX])
+        hipLaunchKernelGGL(k_trtri_border<2>, dim3(tiles * 4), dim3(256), Geo<2>::LDS, st, L, T, U, ld, ra, rw, 1, c0,
+                           c1);
+    else
+        hipLaunchKernelGGL(k_trtri_border<4>, dim3(tiles), dim3(256), GEMM_LDS, st, L, T, U, ld, ra, rw, 1, c0, c1);
+}
+
+// step 2: rows [a, a+w) of the inverse from their finished Wt and the block's own inverse
+void launch_trtri_border2(const double* L, double* T, double* U, int ld, int a, int w, hipStream_t st)
+{
+    const int tiles = a * w;
+    if (tiles <= 0) return;
+    set_big_lds();
+    if (tiles <= g_tune[TUNE_TRTRI_WM2_MAX])
+        hipLaunchKernelGGL(k_trtri_border<2>, dim3(tiles * 4), dim3(256), Geo<2>::LDS, st, L, T, U, ld, a, w, 2, 0, 0);
+    else
+        hipLaunchKernelGGL(k_trtri_border<4>, dim3(tiles), dim3(256), GEMM_LDS, st, L, T, U, ld, a, w, 2, 0, 0);
 }
 
 void launch_lauum(const double* U, double* Kinv, int ld, int a, int w, hipStream_t s)

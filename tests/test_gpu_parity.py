@@ -96,8 +96,8 @@ def test_potrf_potri_vs_oracle(gp_mod, oracle, n):
     assert vec_close(gp_mod.potrs_vec(K, y), oracle.Kinvy(K, y), 1e-11)
 
 
-@pytest.mark.parametrize("n,w,chunk", [(515, 1, 1), (515, 2, 8), (700, 4, 2), (1100, 8, 8), (1100, 2, 3), (1100, 3, 0)])
-def test_inverse_blocks_beside_factorisation(gp_mod, oracle, n, w, chunk):
+@pytest.mark.parametrize("n,w,wm2", [(515, 1, 511), (515, 2, 0), (700, 4, 511), (1100, 8, 511), (1100, 2, 0), (1100, 3, 1 << 20)])
+def test_inverse_blocks_beside_factorisation(gp_mod, oracle, n, w, wm2):
     """K^-1 built block row by block row on the second stream while the factorisation still runs
     (enqueue_potrf with_inverse): ragged last block, one-tile blocks, the default block of 8 tiles."""
     from cugp_amd import capi
@@ -106,12 +106,12 @@ def test_inverse_blocks_beside_factorisation(gp_mod, oracle, n, w, chunk):
     K = M @ M.T + n * np.eye(n)
     Kio = oracle.K_inverse(K)
     capi.check(capi.lib().cugp_set_tuning(3, w))
-    capi.check(capi.lib().cugp_set_tuning(4, chunk))     # k tiles per launch of the bordering product
+    capi.check(capi.lib().cugp_set_tuning(4, wm2))       # bordering step 1: 128- or 64-wide output tiles
     try:
         Ki = gp_mod.potri(K)
     finally:
         capi.check(capi.lib().cugp_set_tuning(3, -1))
-        capi.check(capi.lib().cugp_set_tuning(4, 0))
+        capi.check(capi.lib().cugp_set_tuning(4, 511))
     assert vec_close(Ki, Kio, 1e-11)
     capi.check(capi.lib().cugp_set_tuning(3, 0))         # everything after the factorisation, one stream
     try:

@@ -13,8 +13,8 @@ import cugp_amd.gp as gp                                  # noqa: E402
 from cugp_amd import capi                                 # noqa: E402
 from conftest import synth                                # noqa: E402
 
-KEYS = {"lauum": 0, "trtri": 1, "syrk": 2, "pipe": 3, "chunk": 4}
-DEFAULT = {0: 768, 1: 1200, 2: 384, 3: -1, 4: 0}
+KEYS = {"lauum": 0, "trtri": 1, "syrk": 2, "pipe": 3, "bwm2": 4}
+DEFAULT = {0: 768, 1: 1200, 2: 384, 3: -1, 4: 511}
 n = int(sys.argv[1])
 variants = [dict((KEYS[k], int(v)) for k, v in (kv.split("=") for kv in a.split(","))) if a != "base" else {}
             for a in sys.argv[2:]]
