@@ -1,5 +1,5 @@
 """Three LL+grad evaluations at one size, no profiling events: run under `rocprofv3 --kernel-trace` and feed the
-kernel trace to tools/timeline_report.py.   python3 tools/timeline_run.py <n> [pipe]"""
+kernel trace to tools/timeline_report.py.   python3 tools/timeline_run.py <n> [pipe [key=value ...]]"""
 import os
 import sys
 
@@ -15,6 +15,9 @@ from conftest import synth                                # noqa: E402
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
 if len(sys.argv) > 2:
     capi.check(capi.lib().cugp_set_tuning(3, int(sys.argv[2])))
+for kv in sys.argv[3:]:                                   # further tuning keys as key=value (kernels.h TUNE_*)
+    k, v = kv.split("=")
+    capi.check(capi.lib().cugp_set_tuning(int(k), int(v)))
 X, y = synth(n)
 g = gp.Covsum(n, 10)
 g.set_data(X, y)
