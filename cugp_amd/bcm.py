@@ -44,17 +44,24 @@ class ShardedBCM:
         self.mine = [k for k in range(self.K) if expert_owner(k, world) == rank]
         factory = expert_factory or _default_factory
         self.local = {}
-        for k in self.mine:
-            X, y = experts[k]
-            X = np.ascontiguousarray(X, dtype=np.float64)
-            y = np.ascontiguousarray(y, dtype=np.float64)
-            e = factory(X.shape[0], X.shape[1], device)
-            e.set_data(X, y)
-            self.local[k] = e
-        if len(self.local) > 1:                   # several experts on this GPU already overlap each other
-            for e in self.local.values():         # (as cugp_bcm_create does, csrc/bcm.cpp)
-                if hasattr(e, "set_overlap"):
-                    e.set_overlap(False)
+        self._group = None
+        if expert_factory is None and len(self.mine) > 1:
+            # several experts on this GPU: one library-level BCM evaluates them with shared launches
+            # (csrc/bcm.cpp, group.h); self.local holds borrowed per-expert views for prediction
+            data = [(np.ascontiguousarray(experts[k][0], dtype=np.float64),
+                     np.ascontiguousarray(experts[k][1], dtype=np.float64)) for k in self.mine]
+            self._group = _gp.BCM([X.shape[0] for X, _ in data], data[0][0].shape[1], device)
+            for i, (X, y) in enumerate(data):
+                self._group.set_expert_data(i, X, y)
+                self.local[self.mine[i]] = self._group.expert(i)
+        else:
+            for k in self.mine:
+                X, y = experts[k]
+                X = np.ascontiguousarray(X, dtype=np.float64)
+                y = np.ascontiguousarray(y, dtype=np.float64)
+                e = factory(X.shape[0], X.shape[1], device)
+                e.set_data(X, y)
+                self.local[k] = e
         self.hp = np.zeros(3)
         if comm_device is None:
             comm_device = torch.device("cuda", device) if (world > 1 and dist.get_backend(group) == "nccl") \
@@ -65,6 +72,9 @@ class ShardedBCM:
     # BCM::set_BCM_log_hyperparam (BCM.cpp:123-130): every expert gets the same vector
     def set_loghyper(self, hp):
         self.hp = np.array(hp, dtype=np.float64)
+        if self._group is not None:
+            self._group.set_BCM_log_hyperparam(self.hp)
+            return
         for e in self.local.values():
             e.set_loghyperparam(self.hp)
 
@@ -75,13 +85,16 @@ class ShardedBCM:
 
     def loglik_grad(self):
         """-> (sum_k LL_k, sum_k grad_k, per-expert LL[K]); one collective of K x 4 doubles."""
-        for k in self.mine:                       # all local experts in flight before the first fetch
-            self.local[k].enqueue(True)
         rows = np.zeros((self.K, 4))
-        for k in self.mine:
-            ll, g = self.local[k].fetch()
-            rows[k, 0] = ll
-            rows[k, 1:] = g
+        if self._group is not None:
+            rows[self.mine] = self._group.loglik_grad_rows()
+        else:
+            for k in self.mine:                   # all local experts in flight before the first fetch
+                self.local[k].enqueue(True)
+            for k in self.mine:
+                ll, g = self.local[k].fetch()
+                rows[k, 0] = ll
+                rows[k, 1:] = g
         self._rows.copy_(torch.from_numpy(rows))
         out = self._allreduce(self._rows).cpu().numpy()
         ll, g = 0.0, np.zeros(3)
@@ -124,3 +137,6 @@ class ShardedBCM:
             if hasattr(e, "close"):
                 e.close()
         self.local = {}
+        if self._group is not None:
+            self._group.close()
+            self._group = None

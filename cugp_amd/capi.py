@@ -74,6 +74,7 @@ SIGNATURES = {
     "cugp_bcm_set_loghyper": (C.c_int, [C.c_void_p, _dp]),
     "cugp_bcm_get_loghyper": (C.c_int, [C.c_void_p, _dp]),
     "cugp_bcm_loglik_grad": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
+    "cugp_bcm_loglik_grad_rows": (C.c_int, [C.c_void_p, _dp]),
     "cugp_bcm_predict_partial": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _dp]),
     "cugp_poe_finish": (C.c_int, [_dp, _dp, C.c_int, _dp, _dp]),
     "cugp_bcm_predict": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _dp]),

@@ -3,17 +3,22 @@
 // Mirrors class BCM (distributed_gp/BCM.h:2-27, BCM.cpp): K experts, each a full GP on its own rows,
 // the objective is the plain sum of the experts' log-likelihoods / gradients (BCM.cpp:153-198) and
 // the prediction is a product of experts with no prior-precision correction (BCM.cpp:45-62).
-// Every expert owns its HIP stream, so the evaluations of the experts on one GPU are all enqueued
-// before the first result is fetched and run concurrently; sums are taken in expert order on the
-// host so the result does not depend on completion order.
+// The experts are padded to a common size and evaluated as a GROUP: one sequence of launches in which
+// blockIdx.y selects the expert (group.h) -- 16 experts driven from 16 streams were bounded by the
+// command processor's dispatch rate, not by the CUs.  When a group evaluation is not possible (experts
+// with different hyper-parameters, profiling on) every expert is enqueued on its own stream before the
+// first result is fetched.  Sums are taken in expert order on the host either way, so the result does
+// not depend on completion order.
 #include <cmath>
 #include <cstring>
 #include <new>
 #include <vector>
 
 #include "../../include/cugp.h"
+#include "group.h"
 
 struct cugp_bcm {
+    cugp_group* group = nullptr;     // all experts in one set of launches (null: one expert, or shapes differ)
     std::vector<cugp_gp*> experts;
     std::vector<int> rows;
     int d = 0, device = 0;
@@ -29,15 +34,18 @@ int cugp_bcm_create(int nexperts, const int* rows, int d, int device, cugp_bcm**
     if (!b) return CUGP_ERR_NOMEM;
     b->d = d;
     b->device = device;
+    int nmax = 0;
+    for (int k = 0; k < nexperts; k++) nmax = rows[k] > nmax ? rows[k] : nmax;
     for (int k = 0; k < nexperts; k++) {
         cugp_gp* g = nullptr;
-        int rc = cugp_create(rows[k], d, device, &g);
+        int rc = cugp_create_padded(rows[k], d, device, nmax, &g);   // common padded size (identity padding)
         if (rc) { cugp_bcm_destroy(b); return rc; }
         // several experts on one device already fill each other's idle time; the extra streams only cost launches
         if (nexperts > 1) cugp_set_overlap(g, 0);
         b->experts.push_back(g);
         b->rows.push_back(rows[k]);
     }
+    if (nexperts > 1 && cugp_group_create(b->experts.data(), nexperts, &b->group) != CUGP_OK) b->group = nullptr;
     *out = b;
     return CUGP_OK;
 }
@@ -66,6 +74,7 @@ int cugp_bcm_create_split(const double* X, const double* y, int N, int D, int K,
 int cugp_bcm_destroy(cugp_bcm* b)
 {
     if (!b) return CUGP_OK;
+    cugp_group_destroy(b->group);
     for (cugp_gp* g : b->experts) cugp_destroy(g);
     delete b;
     return CUGP_OK;
@@ -109,18 +118,46 @@ int cugp_bcm_get_loghyper(const cugp_bcm* b, double hp[3])
     return CUGP_OK;
 }
 
+// rows[k] = {LL_k, g_k[0..2]} for every expert of this device (what a multi-device BCM all-reduces)
+int cugp_bcm_loglik_grad_rows(cugp_bcm* b, double* rows)
+{
+    if (!b || !rows) return CUGP_ERR_INVALID;
+    const size_t K = b->experts.size();
+    std::vector<double> lk(K), gk3(3 * K);
+    bool grouped = false;
+    if (b->group) {
+        const int rc = cugp_group_eval(b->group, 1, lk.data(), gk3.data());
+        if (rc == CUGP_OK) grouped = true;
+        else if (rc != CUGP_ERR_INVALID) return rc;      // INVALID: not possible as a group right now
+    }
+    if (!grouped) {
+        for (cugp_gp* e : b->experts) {                  // all experts in flight before the first fetch
+            int rc = cugp_loglik_grad_enqueue(e, 1);
+            if (rc) return rc;
+        }
+        for (size_t k = 0; k < K; k++) {
+            int rc = cugp_loglik_grad_fetch(b->experts[k], &lk[k], &gk3[3 * k]);
+            if (rc) return rc;
+        }
+    }
+    for (size_t k = 0; k < K; k++) {
+        rows[4 * k] = lk[k];
+        for (int i = 0; i < 3; i++) rows[4 * k + 1 + i] = gk3[3 * k + i];
+    }
+    return CUGP_OK;
+}
+
 int cugp_bcm_loglik_grad(cugp_bcm* b, double* ll, double g[3], double* per_expert_ll)
 {
     if (!b) return CUGP_ERR_INVALID;
-    for (cugp_gp* e : b->experts) {                      // all experts in flight before the first fetch
-        int rc = cugp_loglik_grad_enqueue(e, 1);
-        if (rc) return rc;
-    }
+    const size_t K = b->experts.size();
+    std::vector<double> rows(4 * K);
+    int rc = cugp_bcm_loglik_grad_rows(b, rows.data());
+    if (rc) return rc;
     double sll = 0.0, sg[3] = {0, 0, 0};
-    for (size_t k = 0; k < b->experts.size(); k++) {
-        double l, gk[3];
-        int rc = cugp_loglik_grad_fetch(b->experts[k], &l, gk);
-        if (rc) return rc;
+    for (size_t k = 0; k < K; k++) {
+        const double l = rows[4 * k];
+        const double* gk = &rows[4 * k + 1];
         sll = sll + l;                                   // BCM.cpp:190-194
         for (int i = 0; i < 3; i++) sg[i] = (k == 0) ? gk[i] : sg[i] + gk[i];   // BCM.cpp:161-173
         if (per_expert_ll) per_expert_ll[k] = l;

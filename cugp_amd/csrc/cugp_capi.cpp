@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/cugp.h"
+#include "group.h"
 #include "kernels.h"
 
 using namespace cugp;
@@ -46,6 +47,8 @@ int fail(int code, const char* what, hipError_t e = hipSuccess)
 constexpr int NPHASE = 6;
 constexpr int MAX_KEV = 4096;   // per-launch event pairs kept between resets
 constexpr int GRAPH_MAX_TILES = 24;   // evaluations up to 3072 rows are replayed as captured graphs
+constexpr int GROUP_MAX_TILES = 32;   // experts up to 4096 rows share launches; larger ones fill the chip better
+                                      // from their own streams (4 x 6000 rows: 18.3 ms on streams, 19.3 ms grouped)
 constexpr int PROF_STRIDE = 8;  // profiling level 2 times every 8th trailing-update launch, rotating
 
 // One hardware queue per stream up to 16 (the runtime default is 4): the experts of a BCM on one device each
@@ -56,6 +59,14 @@ struct QueueDefault {
 } g_queue_default;
 
 }  // namespace
+
+// set on the lead expert while a group evaluation is being enqueued: every launch then serves all experts
+struct GroupCtx {
+    Batch bt;                       // device table of the experts' buffers, expert count
+    unsigned* tickets = nullptr;    // the experts' step tickets, contiguous [k][nt]
+    double* dout = nullptr;         // results [k][8] on the device ...
+    double* hout = nullptr;         // ... and pinned
+};
 
 struct cugp_gp {
     int n = 0, d = 0, npad = 0, nt = 0, device = 0;
@@ -76,6 +87,7 @@ struct cugp_gp {
     bool inverse_valid = false;    // T, U, Kinv, alpha hold the inverse quantities for (data, hp)
     bool pending = false, pending_grad = false;
     bool joined = true;            // no inverse blocks outstanding on `aux`
+    const GroupCtx* grp = nullptr;  // non-null only inside cugp_group_eval
     bool overlap = true;           // hand inverse blocks to the other streams while the factorisation runs
     // a single-stream evaluation is captured once as a HIP graph and replayed: one launch call instead of
     // ~60 (1500 rows) -- with 16 experts on a GPU the host's launch rate was the bound, not the device
@@ -147,6 +159,8 @@ void drain_kernel_events(cugp_gp* g)
     g->kev_used = 0;
 }
 
+Batch B(const cugp_gp* g) { return g->grp ? g->grp->bt : Batch{}; }
+
 unsigned g_cfg_epoch = 1;          // bumped by cugp_set_tuning: captured graphs carry launch shapes
 
 // block rows per hand-over to the other streams: about an eighth of the matrix (A/B runs at 12..64 tiles),
@@ -167,10 +181,10 @@ int enqueue_inverse_block(cugp_gp* g, int a, int b, bool kinv, hipStream_t x, hi
     const int ld = g->npad, wb = b - a;
     const size_t off = (size_t)a * TILE * ld + (size_t)a * TILE;
     hipStream_t o = xs ? xs : x;
-    launch_trtri_diag(g->dA, ld, a, wb, g->d16, g->dT, g->dU, o);
+    launch_trtri_diag(g->dA, ld, a, wb, g->d16, g->dT, g->dU, o, B(g));
     for (int s = 1; s < wb; s *= 2) {
-        launch_trtri_level(g->dA + off, g->dT + off, g->dU + off, ld, wb, s, 1, o);
-        launch_trtri_level(g->dA + off, g->dT + off, g->dU + off, ld, wb, s, 2, o);
+        launch_trtri_level(g->dA + off, g->dT + off, g->dU + off, ld, wb, s, 1, o, B(g));
+        launch_trtri_level(g->dA + off, g->dT + off, g->dU + off, ld, wb, s, 2, o, B(g));
     }
     if (xs) {
         HIPCHK(hipEventRecord(own_done, xs));
@@ -180,7 +194,7 @@ int enqueue_inverse_block(cugp_gp* g, int a, int b, bool kinv, hipStream_t x, hi
     if (a > 0) launch_trtri_border2(g->dA, g->dT, g->dU, ld, a, wb, x);
     // ... and these rows, now final, go into the Wt of every row below them
     if (b < g->nt) launch_trtri_border1(g->dA, g->dT, g->dU, ld, b, g->nt - b, a, b, x);
-    if (kinv) launch_lauum(g->dU, g->dKinv, ld, a, wb, x);
+    if (kinv) launch_lauum(g->dU, g->dKinv, ld, a, wb, x, B(g));
     return CUGP_OK;
 }
 
@@ -210,10 +224,11 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false)
     const int w = pipe_block(g, with_inverse);
     int nblk = 0, done = 0;                                 // blocks forked so far, block rows handed over
     g->eval_seq++;
-    HIPCHK(hipMemsetAsync(g->dtickets, 0, (size_t)nt * sizeof(unsigned), m));
-    launch_potf2(g->dA, ld, 0, g->d16, g->d64, g->dlogdet, m);
+    if (g->grp) HIPCHK(hipMemsetAsync(g->grp->tickets, 0, (size_t)g->grp->bt.count * nt * sizeof(unsigned), m));
+    else HIPCHK(hipMemsetAsync(g->dtickets, 0, (size_t)nt * sizeof(unsigned), m));
+    launch_potf2(g->dA, ld, 0, g->d16, g->d64, g->dlogdet, m, B(g));
     for (int kb = 0; kb + 1 < nt; kb++) {
-        launch_trsm_inv64(g->dA, g->d64, ld, kb, nt, m);
+        launch_trsm_inv64(g->dA, g->d64, ld, kb, nt, m, B(g));
         // block rows < kb+1 of L are final, and so are the columns <= kb of every row below them
         const int b = kb + 1;
         if (w > 0 && b - done >= w) {
@@ -225,7 +240,7 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false)
         // an event pair around every launch costs several percent of the evaluation
         const bool ev = g->prof >= 2 && (kb + g->eval_seq) % PROF_STRIDE == 0 && g->kev_used + 2 <= (int)g->kev.size();
         if (ev) HIPCHK(hipEventRecord(g->kev[g->kev_used], m));
-        launch_syrk_step(g->dA, ld, kb, nt, g->d16, g->d64, g->dlogdet, g->dtickets, m);
+        launch_syrk_step(g->dA, ld, kb, nt, g->d16, g->d64, g->dlogdet, g->dtickets, m, B(g));
         if (ev) {
             HIPCHK(hipEventRecord(g->kev[g->kev_used + 1], m));
             g->kev_used += 2;
@@ -242,7 +257,7 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false)
         if ((rc = enqueue_inverse_block(g, 0, nt, true, m, nullptr, nullptr))) return rc;
     } else {
         // inverses of all diagonal factor blocks at once (off the factorisation's critical path)
-        launch_trtri_diag(g->dA, ld, 0, nt, g->d16, g->dT, g->dU, m);
+        launch_trtri_diag(g->dA, ld, 0, nt, g->d16, g->dT, g->dU, m, B(g));
     }
     HIPCHK(hipGetLastError());
     return CUGP_OK;
@@ -281,27 +296,32 @@ int record_eval(cugp_gp* g, bool want_grad, const HyperScalars* hd)
     hipStream_t s = g->stream;
     if (hd) HIPCHK(hipMemcpyAsync(g->dhs, g->hhs, sizeof(HyperScalars), hipMemcpyHostToDevice, s));
     if ((rc = phase_mark(g, 0))) return rc;
-    launch_kbuild(g->dX, g->n, g->d, g->npad, h, g->dA, false, s, hd);
+    launch_kbuild(g->dX, g->n, g->d, g->npad, h, g->dA, false, s, hd, B(g));
     if ((rc = phase_mark(g, 1))) return rc;
     if ((rc = enqueue_potrf(g, want_grad, true))) return rc;   // + L^-1 and K^-1, block rows at a time beside it
     if (want_grad) {
         if ((rc = join_inverse(g))) return rc;
         if ((rc = phase_mark(g, 3))) return rc;              // "trtri" phase = what is left of the inverse blocks
         if ((rc = phase_mark(g, 4))) return rc;
-        launch_trmv_lower(g->dT, g->npad, g->npad, g->dy, g->dz, s);        // z = L^-1 y
-        launch_trmv_upper(g->dU, g->npad, g->npad, g->dz, g->dalpha, s);    // alpha = L^-T z
-        launch_trace(g->dX, g->n, g->d, g->npad, h, g->dKinv, g->dalpha, g->dpart, s, hd);
-        launch_finalize(g->dz, g->npad, g->n, g->dlogdet, g->nt, g->dpart, g->nblocks_trace, h, g->dout, s, hd);
+        launch_trmv_lower(g->dT, g->npad, g->npad, g->dy, g->dz, s, B(g));        // z = L^-1 y
+        launch_trmv_upper(g->dU, g->npad, g->npad, g->dz, g->dalpha, s, B(g));    // alpha = L^-T z
+        launch_trace(g->dX, g->n, g->d, g->npad, h, g->dKinv, g->dalpha, g->dpart, s, hd, B(g));
+        launch_finalize(g->dz, g->npad, g->n, g->dlogdet, g->nt, g->dpart, g->nblocks_trace, h, g->dout, s, hd, B(g));
     } else {
         if ((rc = phase_mark(g, 3))) return rc;
         if ((rc = phase_mark(g, 4))) return rc;
-        HIPCHK(hipMemcpyAsync(g->dw, g->dy, (size_t)g->npad * sizeof(double), hipMemcpyDeviceToDevice, s));
-        launch_trsv_lower(g->dA, g->dT, g->npad, g->nt, g->dw, g->dz, s);   // L z = y
-        launch_finalize(g->dz, g->npad, g->n, g->dlogdet, g->nt, nullptr, 0, h, g->dout, s, hd);
+        if (g->grp) launch_copy_y_to_w(g->npad, s, B(g));
+        else HIPCHK(hipMemcpyAsync(g->dw, g->dy, (size_t)g->npad * sizeof(double), hipMemcpyDeviceToDevice, s));
+        launch_trsv_lower(g->dA, g->dT, g->npad, g->nt, g->dw, g->dz, s, B(g));   // L z = y
+        launch_finalize(g->dz, g->npad, g->n, g->dlogdet, g->nt, nullptr, 0, h, g->dout, s, hd, B(g));
     }
     if ((rc = phase_mark(g, 5))) return rc;
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(g->hout, g->dout, 6 * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (g->grp)
+        HIPCHK(hipMemcpyAsync(g->grp->hout, g->grp->dout, (size_t)g->grp->bt.count * 8 * sizeof(double),
+                              hipMemcpyDeviceToHost, s));
+    else
+        HIPCHK(hipMemcpyAsync(g->hout, g->dout, 6 * sizeof(double), hipMemcpyDeviceToHost, s));
     return CUGP_OK;
 }
 
@@ -387,7 +407,9 @@ int cugp_device_count(int* count)
     return CUGP_OK;
 }
 
-int cugp_create(int n, int d, int device, cugp_gp** out)
+int cugp_create(int n, int d, int device, cugp_gp** out) { return cugp_create_padded(n, d, device, 0, out); }
+
+int cugp_create_padded(int n, int d, int device, int npad_min, cugp_gp** out)
 {
     if (!out || n <= 0 || d <= 0) return fail(CUGP_ERR_INVALID, "cugp_create: n, d must be positive");
     int cnt = 0;
@@ -397,7 +419,7 @@ int cugp_create(int n, int d, int device, cugp_gp** out)
     cugp_gp* g = new (std::nothrow) cugp_gp;
     if (!g) return fail(CUGP_ERR_NOMEM, "host allocation");
     g->n = n; g->d = d; g->device = device;
-    g->nt = (n + TILE - 1) / TILE;
+    g->nt = ((n > npad_min ? n : npad_min) + TILE - 1) / TILE;
     g->npad = g->nt * TILE;
     g->nblocks_trace = trace_num_blocks(g->npad);
     *out = nullptr;
@@ -1000,6 +1022,140 @@ int cugp_mfma_peak_tflops(int device, double* tflops)
     const double flop = (double)blocks * 4 /*waves*/ * iters * 8.0 * 2048.0;
     *tflops = flop / (ms * 1e-3) / 1e12;
     (void)hipEventDestroy(a); (void)hipEventDestroy(b); (void)hipFree(sink);
+    return CUGP_OK;
+}
+
+// ---------------------------------------------------------------- grouped evaluation (internal, group.h)
+struct cugp_group {
+    std::vector<cugp_gp*> experts;
+    GroupCtx ctx;
+    ExpertPtrs* dtab = nullptr;
+    bool tab_valid = false;
+    hipGraphExec_t gexec[2] = {nullptr, nullptr};
+    unsigned gepoch[2] = {0, 0};
+};
+
+int cugp_group_create(cugp_gp* const* experts, int k, cugp_group** out)
+{
+    if (!experts || k <= 0 || !out) return CUGP_ERR_INVALID;
+    for (int i = 0; i < k; i++)
+        if (!experts[i] || experts[i]->npad != experts[0]->npad || experts[i]->d != experts[0]->d ||
+            experts[i]->device != experts[0]->device)
+            return CUGP_ERR_INVALID;
+    cugp_group* gr = new (std::nothrow) cugp_group;
+    if (!gr) return fail(CUGP_ERR_NOMEM, "host allocation");
+    gr->experts.assign(experts, experts + k);
+    const int nt = experts[0]->nt;
+    hipError_t e = hipSetDevice(experts[0]->device);
+    if (e == hipSuccess) e = hipMalloc((void**)&gr->dtab, (size_t)k * sizeof(ExpertPtrs));
+    if (e == hipSuccess) e = hipMalloc((void**)&gr->ctx.tickets, (size_t)k * nt * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc((void**)&gr->ctx.dout, (size_t)k * 8 * sizeof(double));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&gr->ctx.hout, (size_t)k * 8 * sizeof(double), hipHostMallocDefault);
+    if (e != hipSuccess) {
+        cugp_group_destroy(gr);
+        return fail(e == hipErrorOutOfMemory ? CUGP_ERR_NOMEM : CUGP_ERR_DEVICE, "cugp_group_create", e);
+    }
+    gr->ctx.bt.tab = gr->dtab;
+    gr->ctx.bt.count = k;
+    *out = gr;
+    return CUGP_OK;
+}
+
+void cugp_group_destroy(cugp_group* gr)
+{
+    if (!gr) return;
+    if (!gr->experts.empty()) {
+        (void)hipSetDevice(gr->experts[0]->device);
+        (void)hipStreamSynchronize(gr->experts[0]->stream);
+    }
+    for (hipGraphExec_t x : gr->gexec)
+        if (x) (void)hipGraphExecDestroy(x);
+    if (gr->dtab) (void)hipFree(gr->dtab);
+    if (gr->ctx.tickets) (void)hipFree(gr->ctx.tickets);
+    if (gr->ctx.dout) (void)hipFree(gr->ctx.dout);
+    if (gr->ctx.hout) (void)hipHostFree(gr->ctx.hout);
+    delete gr;
+}
+
+int cugp_group_eval(cugp_group* gr, int want_grad, double* ll, double* g)
+{
+    if (!gr || !ll) return CUGP_ERR_INVALID;
+    cugp_gp* lead = gr->experts[0];
+    const int k = (int)gr->experts.size(), nt = lead->nt;
+    int rc;
+    if (nt > GROUP_MAX_TILES) return CUGP_ERR_INVALID;
+    for (cugp_gp* e : gr->experts) {
+        if (!e->have_data || e->prof != 0 || pipe_block(e, want_grad != 0) != 0) return CUGP_ERR_INVALID;
+        if (e->hp[0] != lead->hp[0] || e->hp[1] != lead->hp[1] || e->hp[2] != lead->hp[2]) return CUGP_ERR_INVALID;
+    }
+    if ((rc = use_device(lead))) return rc;
+    for (cugp_gp* e : gr->experts) {
+        if ((rc = fetch_eval(e))) return rc;
+        const bool had = e->dA && e->dT && e->dU && (!want_grad || e->dKinv);
+        if ((rc = ensure_factor_bufs(e))) return rc;
+        if (want_grad && (rc = ensure_inverse_bufs(e))) return rc;
+        if (!had) gr->tab_valid = false;
+    }
+    if (!gr->tab_valid) {
+        std::vector<ExpertPtrs> tab(k);
+        for (int i = 0; i < k; i++) {
+            cugp_gp* e = gr->experts[i];
+            tab[i] = ExpertPtrs{e->dA, e->dT, e->dU, e->dKinv, e->d16, e->d64, e->dlogdet, e->dy, e->dz, e->dalpha,
+                                e->dw, e->dpart, gr->ctx.dout + (size_t)i * 8, e->dX,
+                                gr->ctx.tickets + (size_t)i * nt, e->n};
+        }
+        HIPCHK(hipStreamSynchronize(lead->stream));           // a captured graph may still be reading the old table
+        HIPCHK(hipMemcpy(gr->dtab, tab.data(), tab.size() * sizeof(ExpertPtrs), hipMemcpyHostToDevice));
+        gr->tab_valid = true;
+    }
+    for (cugp_gp* e : gr->experts) e->factor_valid = e->inverse_valid = false;
+    *lead->hhs = scalars(lead);
+    lead->grp = &gr->ctx;
+    const int gi = want_grad ? 1 : 0;
+    if (g_tune[TUNE_GRAPHS] != 0 && nt <= GRAPH_MAX_TILES) {
+        if (!gr->gexec[gi] || gr->gepoch[gi] != g_cfg_epoch) {
+            if (gr->gexec[gi]) (void)hipGraphExecDestroy(gr->gexec[gi]);
+            gr->gexec[gi] = nullptr;
+            prepare_kernels();
+            hipGraph_t graph_obj = nullptr;
+            hipError_t e = hipStreamBeginCapture(lead->stream, hipStreamCaptureModeThreadLocal);
+            if (e != hipSuccess) { lead->grp = nullptr; return fail(CUGP_ERR_DEVICE, "hipStreamBeginCapture", e); }
+            rc = record_eval(lead, want_grad != 0, lead->dhs);
+            e = hipStreamEndCapture(lead->stream, &graph_obj);   // always leave capture mode
+            if (rc == CUGP_OK && e == hipSuccess) e = hipGraphInstantiate(&gr->gexec[gi], graph_obj, nullptr, nullptr, 0);
+            if (graph_obj) (void)hipGraphDestroy(graph_obj);
+            if (rc || e != hipSuccess) {
+                gr->gexec[gi] = nullptr;
+                lead->grp = nullptr;
+                return rc ? rc : fail(CUGP_ERR_DEVICE, "group graph capture", e);
+            }
+            gr->gepoch[gi] = g_cfg_epoch;
+        }
+        rc = CUGP_OK;
+        const hipError_t e = hipGraphLaunch(gr->gexec[gi], lead->stream);
+        if (e != hipSuccess) rc = fail(CUGP_ERR_DEVICE, "hipGraphLaunch", e);
+    } else {
+        rc = record_eval(lead, want_grad != 0, lead->dhs);
+    }
+    lead->grp = nullptr;
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(lead->stream));
+    for (int i = 0; i < k; i++) {
+        cugp_gp* e = gr->experts[i];
+        const double* h = gr->ctx.hout + (size_t)i * 8;
+        e->last_ll = h[0];
+        e->last_quad = h[4];
+        e->last_logdet = h[5];
+        e->factor_valid = true;
+        ll[i] = h[0];
+        if (want_grad) {
+            for (int j = 0; j < 3; j++) {
+                e->last_g[j] = h[1 + j];
+                if (g) g[3 * i + j] = h[1 + j];
+            }
+            e->inverse_valid = true;
+        }
+    }
     return CUGP_OK;
 }
 

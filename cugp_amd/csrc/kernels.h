@@ -17,6 +17,23 @@ enum { TUNE_LAUUM_WM2_MAX = 0,   // K^-1 product: use 64x64 tiles when there are
        TUNE_COUNT = 6 };
 extern int g_tune[TUNE_COUNT];
 
+struct HyperScalars;
+
+// Batched launches: the experts of a BCM on one device have the same shapes, so one launch can serve all of
+// them -- blockIdx.y picks the expert and the kernel takes its buffers from a device-resident table instead
+// of its pointer arguments.  (16 experts x ~45 launches per evaluation from 16 streams were bounded by the
+// command processor, not by the CUs.)
+struct ExpertPtrs {
+    double *A, *T, *U, *Kinv, *d16, *d64, *logdet, *y, *z, *alpha, *w, *part, *out;
+    const double* X;
+    unsigned* tickets;
+    int n;
+};
+struct Batch {
+    const ExpertPtrs* tab = nullptr;   // nullptr: one expert, buffers from the arguments
+    int count = 1;
+};
+
 struct HyperScalars {              // exp(2*theta) evaluated on the host, as the reference does (covkernel.cpp:65-67)
     double ell_sq, signal_var, noise_var;
 };
@@ -25,7 +42,7 @@ struct HyperScalars {              // exp(2*theta) evaluated on the host, as the
 // lower 64x64 tiles of K (+ mirror when `full`), padding rows/cols >= n set to identity
 // hd (optional, also below): read the hyper-scalars from device memory instead of the argument
 void launch_kbuild(const double* X, int n, int d, int npad, HyperScalars h, double* K, bool full,
-                   hipStream_t s, const HyperScalars* hd = nullptr);
+                   hipStream_t s, const HyperScalars* hd = nullptr, Batch bt = {});
 // S[i][j] = |x_i - x_j|^2 / c, zero diagonal, full symmetric (N2, covkernel.cpp:130-157)
 void launch_sqdist(const double* X, int n, int d, int npad, double c, double* S, hipStream_t s);
 // Ks[t][i] = sf2 * exp(-0.5*|x_i - xt_t|^2 / l^2), row-major nt_pad x npad (pad = 0)   (N12)
@@ -34,23 +51,25 @@ void launch_kcross(const double* X, int n, int d, int npad, const double* Xt, in
 
 // ---- blocked right-looking Cholesky (N4) on the lower triangle of A (npad x npad, ld = npad) ----
 // d16: 16x16 diagonal inverses [nt][8][256]; d64: the two 64x64 diagonal inverses of each block [nt][2][4096]
-void launch_potf2(double* A, int ld, int kb, double* d16, double* d64, double* logdet_part, hipStream_t s);
-void launch_trsm_inv64(double* A, const double* d64, int ld, int kb, int nt, hipStream_t s);     // 3-phase, 64x64 inverses
+void launch_potf2(double* A, int ld, int kb, double* d16, double* d64, double* logdet_part, hipStream_t s,
+                  Batch bt = {});
+void launch_trsm_inv64(double* A, const double* d64, int ld, int kb, int nt, hipStream_t s, Batch bt = {});   // 3-phase, 64x64 inverses
 void launch_trtri_diag(const double* A, int ld, int kb, int nblocks, const double* d16, double* T, double* U,
-                       hipStream_t s);
+                       hipStream_t s, Batch bt = {});
 // trailing update of step kb fused with the factorisation of diagonal block kb+1 (tickets[kb] must be 0)
 void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* d64, double* logdet_part,
-                      unsigned* tickets, hipStream_t s);    // tile (kb+1,kb+1) only, fine grained
+                      unsigned* tickets, hipStream_t s, Batch bt = {});
 
 // ---- triangular inverse by recursive doubling (N7) and K^-1 = U U^T (N8) ----
-void launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, int s, int step, hipStream_t st);
+void launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, int s, int step, hipStream_t st,
+                        Batch bt = {});
 // bordering step 1, one k chunk: Wt(tj < c1, ti in [ra, ra+rw)) (+)= sum_{k in [max(tj,c0), c1)} U[tj][k] L[ti][k]
 void launch_trtri_border1(const double* L, double* T, double* U, int ld, int ra, int rw, int c0, int c1,
                           hipStream_t st);
 // bordering step 2: rows [a, a+w) of the inverse from their finished Wt and the block's own inverse
 void launch_trtri_border2(const double* L, double* T, double* U, int ld, int a, int w, hipStream_t st);
 // Kinv(lower tiles < a+w) (+)= contribution of inverse rows [a, a+w); a = 0, w = nt: the whole product
-void launch_lauum(const double* U, double* Kinv, int ld, int a, int w, hipStream_t s);
+void launch_lauum(const double* U, double* Kinv, int ld, int a, int w, hipStream_t s, Batch bt = {});
 
 // ---- prediction products ----
 // W[t][i] = sum_{k<=i} Ks[t][k] T[i][k]   (nt_pad x npad, row-major)
@@ -59,17 +78,22 @@ void launch_predict_finish(const double* Ks, const double* W, const double* alph
                            HyperScalars h, double* mean, double* var, hipStream_t s);
 
 // ---- vector kernels ----
-void launch_trmv_lower(const double* T, int ld, int npad, const double* x, double* z, hipStream_t s);  // z = T x
-void launch_trmv_upper(const double* U, int ld, int npad, const double* x, double* a, hipStream_t s);  // a = U x
+void launch_trmv_lower(const double* T, int ld, int npad, const double* x, double* z, hipStream_t s,
+                       Batch bt = {});                                                                 // z = T x
+void launch_trmv_upper(const double* U, int ld, int npad, const double* x, double* a, hipStream_t s,
+                       Batch bt = {});                                                                 // a = U x
 void launch_trsv_lower(const double* A, const double* T, int ld, int nt, const double* y, double* z,
-                       hipStream_t s);                                                                 // L z = y
+                       hipStream_t s, Batch bt = {});                                                  // L z = y
+void launch_copy_y_to_w(int npad, hipStream_t s, Batch bt);                                            // batched only
 // gradient traces (N10+N11 fused): partial sums per block into part[3*nblocks]
 int trace_num_blocks(int npad);
 void launch_trace(const double* X, int n, int d, int npad, HyperScalars h, const double* Kinv,
-                  const double* alpha, double* part, hipStream_t s, const HyperScalars* hd = nullptr);
+                  const double* alpha, double* part, hipStream_t s, const HyperScalars* hd = nullptr,
+                  Batch bt = {});
 // out[0..3] = LL, g0, g1, g2  (LL only when part == nullptr)
 void launch_finalize(const double* z, int npad, int n, const double* logdet_part, int nt, const double* part,
-                     int nblocks, HyperScalars h, double* out, hipStream_t s, const HyperScalars* hd = nullptr);
+                     int nblocks, HyperScalars h, double* out, hipStream_t s, const HyperScalars* hd = nullptr,
+                     Batch bt = {});
 // one-time function attributes (dynamic LDS sizes); the launchers do it lazily, a stream capture must not
 void prepare_kernels();
 

@@ -274,8 +274,9 @@ __device__ __forceinline__ void tri_index(int idx, int& ti, int& tj)
 // for tj <= ti < a+w.  a = 0, w = nt is the whole product in one launch.
 template <int WM>
 __global__ __launch_bounds__(256, 2) void k_lauum(const double* __restrict__ U, double* __restrict__ Kinv, int ld,
-                                                  int a, int w)
+                                                  int a, int w, const ExpertPtrs* __restrict__ bt)
 {
+    if (bt) { U = bt[blockIdx.y].U; Kinv = bt[blockIdx.y].Kinv; }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SUB = 4 / WM, BT = 32 * WM;
     int ti, tj;
@@ -324,8 +325,10 @@ __device__ __forceinline__ void trtri_tile(const double* __restrict__ L, double*
 // one level of recursive doubling: all pairs of s-tile blocks at once
 template <int WM>
 __global__ __launch_bounds__(256, 2) void k_trtri_level(const double* __restrict__ L, double* __restrict__ T,
-                                                        double* __restrict__ U, int ld, int nt, int s, int step)
+                                                        double* __restrict__ U, int ld, int nt, int s, int step,
+                                                        const ExpertPtrs* __restrict__ bt)
 {
+    if (bt) { L = bt[blockIdx.y].A; T = bt[blockIdx.y].T; U = bt[blockIdx.y].U; }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SUB = 4 / WM;
     const int blk = blockIdx.x / (SUB * SUB), sub = blockIdx.x % (SUB * SUB);
@@ -415,8 +418,9 @@ __global__ __launch_bounds__(256) void k_mfma_peak(double* sink, int iters)
 // tiles the other waves need pass through 8 KiB of LDS.  <= 48 dependent MFMAs per wave (was 144).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_trsm_inv64(double* __restrict__ A, const double* __restrict__ d64,
-                                                    int ld, int kb)
+                                                    int ld, int kb, const ExpertPtrs* __restrict__ bt)
 {
+    if (bt) { A = bt[blockIdx.y].A; d64 = bt[blockIdx.y].d64; }
     __shared__ double xbuf[4][4][64];
     __builtin_amdgcn_s_setprio(3);                      // on the factorisation's serial chain (see k_syrk_step)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -524,8 +528,9 @@ __device__ __forceinline__ void sqdist_4x4(const double* __restrict__ X, const d
 // with new hyper-parameters by refreshing that one buffer instead of every kernel's arguments
 __global__ __launch_bounds__(256) void k_build(const double* __restrict__ X, int n, int d, int npad,
                                                HyperScalars h_arg, const HyperScalars* __restrict__ hd,
-                                               double* __restrict__ K, int full)
+                                               double* __restrict__ K, int full, const ExpertPtrs* __restrict__ bt)
 {
+    if (bt) { X = bt[blockIdx.y].X; n = bt[blockIdx.y].n; K = bt[blockIdx.y].A; }
     const HyperScalars h = hd ? *hd : h_arg;
     __shared__ double xs[KT][DC + 1], ys[KT][DC + 1];
     int ti, tj;
@@ -920,8 +925,10 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ Ab, int ld, doub
 }
 
 __global__ __launch_bounds__(256) void k_potf2(double* __restrict__ A, int ld, int kb, double* __restrict__ d16,
-                                               double* __restrict__ d64, double* __restrict__ logdet_part)
+                                               double* __restrict__ d64, double* __restrict__ logdet_part,
+                                               const ExpertPtrs* __restrict__ bt)
 {
+    if (bt) { A = bt[blockIdx.y].A; d16 = bt[blockIdx.y].d16; d64 = bt[blockIdx.y].d64; logdet_part = bt[blockIdx.y].logdet; }
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ double red[TILE];
     potf2_body(A + (size_t)kb * TILE * ld + kb * TILE, ld, d16 + (size_t)kb * NMT * (MT * MT),
@@ -974,8 +981,13 @@ static_assert(POTF2_LDS >= GEMM_LDS, "the fused step kernel sizes its LDS for bo
 __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, int ld, int kb,
                                                       double* __restrict__ d16, double* __restrict__ d64,
                                                       double* __restrict__ logdet_part,
-                                                      unsigned* __restrict__ tickets, int nfull)
+                                                      unsigned* __restrict__ tickets, int nfull,
+                                                      const ExpertPtrs* __restrict__ bt)
 {
+    if (bt) {
+        const ExpertPtrs& e = bt[blockIdx.y];
+        A = e.A; d16 = e.d16; d64 = e.d64; logdet_part = e.logdet; tickets = e.tickets;
+    }
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ double red[TILE];
     __shared__ unsigned s_ticket;
@@ -1038,8 +1050,9 @@ __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, in
 // writes T (lower, zeros above) and U = T^T (upper, zeros below).  blockIdx.x = block offset from kb.
 __global__ __launch_bounds__(256) void k_trtri_diag(const double* __restrict__ A, int ld, int kb,
                                                     const double* __restrict__ d16, double* __restrict__ T,
-                                                    double* __restrict__ U)
+                                                    double* __restrict__ U, const ExpertPtrs* __restrict__ bt)
 {
+    if (bt) { A = bt[blockIdx.y].A; d16 = bt[blockIdx.y].d16; T = bt[blockIdx.y].T; U = bt[blockIdx.y].U; }
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* ytmp = sm + TILE * PLD;                             // [(TILE-16)][17]
     const int t = threadIdx.x;
@@ -1102,8 +1115,10 @@ __device__ __forceinline__ double wave_sum(double v)
 
 // z[i] = sum_{k < (ti+1)*128} T[i][k] x[k]  (one wave per row; the diagonal tile is zero above the diagonal)
 __global__ __launch_bounds__(256) void k_trmv_lower(const double* __restrict__ T, int ld, int npad,
-                                                    const double* __restrict__ x, double* __restrict__ z)
+                                                    const double* __restrict__ x, double* __restrict__ z,
+                                                    const ExpertPtrs* __restrict__ bt)
 {
+    if (bt) { T = bt[blockIdx.y].T; x = bt[blockIdx.y].y; z = bt[blockIdx.y].z; }
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= npad) return;
     const int kend = (row / TILE + 1) * TILE;
@@ -1119,8 +1134,10 @@ __global__ __launch_bounds__(256) void k_trmv_lower(const double* __restrict__ T
 
 // a[i] = sum_{k >= ti*128} U[i][k] x[k]
 __global__ __launch_bounds__(256) void k_trmv_upper(const double* __restrict__ U, int ld, int npad,
-                                                    const double* __restrict__ x, double* __restrict__ a)
+                                                    const double* __restrict__ x, double* __restrict__ a,
+                                                    const ExpertPtrs* __restrict__ bt)
 {
+    if (bt) { U = bt[blockIdx.y].U; x = bt[blockIdx.y].z; a = bt[blockIdx.y].alpha; }
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= npad) return;
     const int kbeg = (row / TILE) * TILE;
@@ -1134,10 +1151,19 @@ __global__ __launch_bounds__(256) void k_trmv_upper(const double* __restrict__ U
     if (lane == 0) a[row] = s;
 }
 
+// w = y for every expert of a batched launch (the forward substitution consumes w)
+__global__ __launch_bounds__(256) void k_copy_y_to_w(int npad, const ExpertPtrs* __restrict__ bt)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < npad) bt[blockIdx.y].w[i] = bt[blockIdx.y].y[i];
+}
+
 // blocked forward substitution L z = y (LL-only path): step kb = (1) z_kb = T_kk w_kb, (2) w[rows below] -= L21 z_kb
 __global__ __launch_bounds__(256) void k_trsv_diag(const double* __restrict__ T, int ld, int kb,
-                                                   const double* __restrict__ w, double* __restrict__ z)
+                                                   const double* __restrict__ w, double* __restrict__ z,
+                                                   const ExpertPtrs* __restrict__ bt)
 {
+    if (bt) { T = bt[blockIdx.y].T; w = bt[blockIdx.y].w; z = bt[blockIdx.y].z; }
     // z_kb = T_kk w_kb (128x128, lower): two threads per row, 64 columns each, 16-byte loads
     __shared__ double ws[TILE];
     const int k0 = kb * TILE, t = threadIdx.x;
@@ -1158,8 +1184,10 @@ __global__ __launch_bounds__(256) void k_trsv_diag(const double* __restrict__ T,
 }
 
 __global__ __launch_bounds__(256) void k_trsv_update(const double* __restrict__ A, int ld, int kb, int npad,
-                                                     const double* __restrict__ z, double* __restrict__ w)
+                                                     const double* __restrict__ z, double* __restrict__ w,
+                                                     const ExpertPtrs* __restrict__ bt)
 {
+    if (bt) { A = bt[blockIdx.y].A; z = bt[blockIdx.y].z; w = bt[blockIdx.y].w; }
     const int k0 = kb * TILE;
     const int row = k0 + TILE + blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= npad) return;
@@ -1174,8 +1202,12 @@ __global__ __launch_bounds__(256) void k_trsv_update(const double* __restrict__ 
 __global__ __launch_bounds__(256) void k_trace(const double* __restrict__ X, int n, int d, int npad,
                                                HyperScalars h_arg, const HyperScalars* __restrict__ hd,
                                                const double* __restrict__ Kinv, const double* __restrict__ alpha,
-                                               double* __restrict__ part)
+                                               double* __restrict__ part, const ExpertPtrs* __restrict__ bt)
 {
+    if (bt) {
+        const ExpertPtrs& e = bt[blockIdx.y];
+        X = e.X; n = e.n; Kinv = e.Kinv; alpha = e.alpha; part = e.part;
+    }
     const HyperScalars h = hd ? *hd : h_arg;
     __shared__ double xs[KT][DC + 1], ys[KT][DC + 1];
     __shared__ double red[3][4];
@@ -1228,8 +1260,13 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ z, 
                                                   const double* __restrict__ logdet_part, int nt,
                                                   const double* __restrict__ part, int nblocks,
                                                   HyperScalars h_arg, const HyperScalars* __restrict__ hd,
-                                                  double* __restrict__ out)
+                                                  double* __restrict__ out, const ExpertPtrs* __restrict__ bt)
 {
+    if (bt) {
+        const ExpertPtrs& e = bt[blockIdx.y];
+        z = e.z; n = e.n; logdet_part = e.logdet; out = e.out;
+        if (part) part = e.part;
+    }
     const HyperScalars h = hd ? *hd : h_arg;
     __shared__ double red[5][256];
     const int t = threadIdx.x;
@@ -1289,16 +1326,17 @@ int g_tune[TUNE_COUNT] = {768, 1200, 384, -1, 511, 1};   // defaults chosen by i
 static inline int tri_count(int n) { return n * (n + 1) / 2; }
 
 void launch_kbuild(const double* X, int n, int d, int npad, HyperScalars h, double* K, bool full, hipStream_t s,
-                   const HyperScalars* hd)
+                   const HyperScalars* hd, Batch bt)
 {
-    hipLaunchKernelGGL(k_build, dim3(tri_count(npad / KT)), dim3(256), 0, s, X, n, d, npad, h, hd, K, full ? 1 : 0);
+    hipLaunchKernelGGL(k_build, dim3(tri_count(npad / KT), bt.count), dim3(256), 0, s, X, n, d, npad, h, hd, K,
+                       full ? 1 : 0, bt.tab);
 }
 
 void launch_sqdist(const double* X, int n, int d, int npad, double c, double* S, hipStream_t s)
 {
     HyperScalars h{c, 0.0, 0.0};
     hipLaunchKernelGGL(k_build, dim3(tri_count(npad / KT)), dim3(256), 0, s, X, n, d, npad, h,
-                       (const HyperScalars*)nullptr, S, 2);
+                       (const HyperScalars*)nullptr, S, 2, (const ExpertPtrs*)nullptr);
 }
 
 void launch_kcross(const double* X, int n, int d, int npad, const double* Xt, int nt, int ntpad, HyperScalars h,
@@ -1323,28 +1361,28 @@ static void set_big_lds()
 
 void prepare_kernels() { set_big_lds(); }
 
-void launch_potf2(double* A, int ld, int kb, double* d16, double* d64, double* logdet_part, hipStream_t s)
+void launch_potf2(double* A, int ld, int kb, double* d16, double* d64, double* logdet_part, hipStream_t s, Batch bt)
 {
     set_big_lds();
-    hipLaunchKernelGGL(k_potf2, dim3(1), dim3(256), POTF2_LDS, s, A, ld, kb, d16, d64, logdet_part);
+    hipLaunchKernelGGL(k_potf2, dim3(1, bt.count), dim3(256), POTF2_LDS, s, A, ld, kb, d16, d64, logdet_part, bt.tab);
 }
 
-void launch_trsm_inv64(double* A, const double* d64, int ld, int kb, int nt, hipStream_t s)
+void launch_trsm_inv64(double* A, const double* d64, int ld, int kb, int nt, hipStream_t s, Batch bt)
 {
     const int nstrips = (nt - kb - 1) * (TILE / MT);
     if (nstrips <= 0) return;
-    hipLaunchKernelGGL(k_trsm_inv64, dim3(nstrips), dim3(256), 0, s, A, d64, ld, kb);
+    hipLaunchKernelGGL(k_trsm_inv64, dim3(nstrips, bt.count), dim3(256), 0, s, A, d64, ld, kb, bt.tab);
 }
 
 void launch_trtri_diag(const double* A, int ld, int kb, int nblocks, const double* d16, double* T, double* U,
-                       hipStream_t s)
+                       hipStream_t s, Batch bt)
 {
     set_big_lds();
-    hipLaunchKernelGGL(k_trtri_diag, dim3(nblocks), dim3(256), TRTRI_LDS, s, A, ld, kb, d16, T, U);
+    hipLaunchKernelGGL(k_trtri_diag, dim3(nblocks, bt.count), dim3(256), TRTRI_LDS, s, A, ld, kb, d16, T, U, bt.tab);
 }
 
 void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* d64, double* logdet_part,
-                      unsigned* tickets, hipStream_t s)
+                      unsigned* tickets, hipStream_t s, Batch bt)
 {
     const int m = nt - kb - 1;
     if (m <= 0) return;
@@ -1354,11 +1392,12 @@ void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* d6
     const int ntl = tri_count(m) - 1;
     int nfull = ntl;
     if (ntl >= 512 && (ntl % 512) <= g_tune[TUNE_SYRK_REM_MAX]) nfull = ntl - ntl % 512;
-    hipLaunchKernelGGL(k_syrk_step, dim3(NDIAGWG + nfull + 4 * (ntl - nfull)), dim3(256), STEP_LDS, s, A, ld, kb, d16,
-                       d64, logdet_part, tickets, nfull);
+    hipLaunchKernelGGL(k_syrk_step, dim3(NDIAGWG + nfull + 4 * (ntl - nfull), bt.count), dim3(256), STEP_LDS, s, A, ld,
+                       kb, d16, d64, logdet_part, tickets, nfull, bt.tab);
 }
 
-void launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, int s, int step, hipStream_t st)
+void launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, int s, int step, hipStream_t st,
+                        Batch bt)
 {
     // pairs p = 0.. : A = [2ps, 2ps+s), B = [2ps+s, min(2ps+2s, nt)); count tiles |A| x |B|
     int tiles = 0;
@@ -1371,9 +1410,11 @@ void launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, i
     // few 128-tiles cannot fill 512 workgroup slots: use 64x64 output tiles (4x the parallelism) there
     set_big_lds();
     if (tiles <= g_tune[TUNE_TRTRI_WM2_MAX])
-        hipLaunchKernelGGL(k_trtri_level<2>, dim3(tiles * 4), dim3(256), Geo<2>::LDS, st, L, T, U, ld, nt, s, step);
+        hipLaunchKernelGGL(k_trtri_level<2>, dim3(tiles * 4, bt.count), dim3(256), Geo<2>::LDS, st, L, T, U, ld, nt, s,
+                           step, bt.tab);
     else
-        hipLaunchKernelGGL(k_trtri_level<4>, dim3(tiles), dim3(256), GEMM_LDS, st, L, T, U, ld, nt, s, step);
+        hipLaunchKernelGGL(k_trtri_level<4>, dim3(tiles, bt.count), dim3(256), GEMM_LDS, st, L, T, U, ld, nt, s, step,
+                           bt.tab);
 }
 
 // step 1 of the bordering, spread over time: add the k tiles [c0, c1) (a block of inverse rows that just
@@ -1403,14 +1444,14 @@ void launch_trtri_border2(const double* L, double* T, double* U, int ld, int a, 
         hipLaunchKernelGGL(k_trtri_border<4>, dim3(tiles), dim3(256), GEMM_LDS, st, L, T, U, ld, a, w, 2, 0, 0);
 }
 
-void launch_lauum(const double* U, double* Kinv, int ld, int a, int w, hipStream_t s)
+void launch_lauum(const double* U, double* Kinv, int ld, int a, int w, hipStream_t s, Batch bt)
 {
     set_big_lds();
     const int tiles = tri_count(a + w);
     if (tiles <= g_tune[TUNE_LAUUM_WM2_MAX])
-        hipLaunchKernelGGL(k_lauum<2>, dim3(tiles * 4), dim3(256), Geo<2>::LDS, s, U, Kinv, ld, a, w);
+        hipLaunchKernelGGL(k_lauum<2>, dim3(tiles * 4, bt.count), dim3(256), Geo<2>::LDS, s, U, Kinv, ld, a, w, bt.tab);
     else
-        hipLaunchKernelGGL(k_lauum<4>, dim3(tiles), dim3(256), GEMM_LDS, s, U, Kinv, ld, a, w);
+        hipLaunchKernelGGL(k_lauum<4>, dim3(tiles, bt.count), dim3(256), GEMM_LDS, s, U, Kinv, ld, a, w, bt.tab);
 }
 
 void launch_predict_gemm(const double* Ks, const double* T, double* W, int ld, int ntt, int nt, hipStream_t s)
@@ -1426,41 +1467,49 @@ void launch_predict_finish(const double* Ks, const double* W, const double* alph
                        mean, var);
 }
 
-void launch_trmv_lower(const double* T, int ld, int npad, const double* x, double* z, hipStream_t s)
+void launch_trmv_lower(const double* T, int ld, int npad, const double* x, double* z, hipStream_t s, Batch bt)
 {
-    hipLaunchKernelGGL(k_trmv_lower, dim3(npad / 4), dim3(256), 0, s, T, ld, npad, x, z);
+    hipLaunchKernelGGL(k_trmv_lower, dim3(npad / 4, bt.count), dim3(256), 0, s, T, ld, npad, x, z, bt.tab);
 }
 
-void launch_trmv_upper(const double* U, int ld, int npad, const double* x, double* a, hipStream_t s)
+void launch_trmv_upper(const double* U, int ld, int npad, const double* x, double* a, hipStream_t s, Batch bt)
 {
-    hipLaunchKernelGGL(k_trmv_upper, dim3(npad / 4), dim3(256), 0, s, U, ld, npad, x, a);
+    hipLaunchKernelGGL(k_trmv_upper, dim3(npad / 4, bt.count), dim3(256), 0, s, U, ld, npad, x, a, bt.tab);
 }
 
-void launch_trsv_lower(const double* A, const double* T, int ld, int nt, const double* y, double* z, hipStream_t s)
+void launch_copy_y_to_w(int npad, hipStream_t s, Batch bt)
+{
+    hipLaunchKernelGGL(k_copy_y_to_w, dim3((npad + 255) / 256, bt.count), dim3(256), 0, s, npad, bt.tab);
+}
+
+void launch_trsv_lower(const double* A, const double* T, int ld, int nt, const double* y, double* z, hipStream_t s,
+                       Batch bt)
 {
     // y is consumed as the running right-hand side w (caller passes a scratch copy)
     double* w = const_cast<double*>(y);
     const int npad = nt * TILE;
     for (int kb = 0; kb < nt; kb++) {
-        hipLaunchKernelGGL(k_trsv_diag, dim3(1), dim3(256), 0, s, T, ld, kb, w, z);
+        hipLaunchKernelGGL(k_trsv_diag, dim3(1, bt.count), dim3(256), 0, s, T, ld, kb, w, z, bt.tab);
         const int rows = npad - (kb + 1) * TILE;
         if (rows > 0)
-            hipLaunchKernelGGL(k_trsv_update, dim3(rows / 4), dim3(256), 0, s, A, ld, kb, npad, z, w);
+            hipLaunchKernelGGL(k_trsv_update, dim3(rows / 4, bt.count), dim3(256), 0, s, A, ld, kb, npad, z, w, bt.tab);
     }
 }
 
 int trace_num_blocks(int npad) { return tri_count(npad / KT); }
 
 void launch_trace(const double* X, int n, int d, int npad, HyperScalars h, const double* Kinv, const double* alpha,
-                  double* part, hipStream_t s, const HyperScalars* hd)
+                  double* part, hipStream_t s, const HyperScalars* hd, Batch bt)
 {
-    hipLaunchKernelGGL(k_trace, dim3(tri_count(npad / KT)), dim3(256), 0, s, X, n, d, npad, h, hd, Kinv, alpha, part);
+    hipLaunchKernelGGL(k_trace, dim3(tri_count(npad / KT), bt.count), dim3(256), 0, s, X, n, d, npad, h, hd, Kinv,
+                       alpha, part, bt.tab);
 }
 
 void launch_finalize(const double* z, int npad, int n, const double* logdet_part, int nt, const double* part,
-                     int nblocks, HyperScalars h, double* out, hipStream_t s, const HyperScalars* hd)
+                     int nblocks, HyperScalars h, double* out, hipStream_t s, const HyperScalars* hd, Batch bt)
 {
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, s, z, npad, n, logdet_part, nt, part, nblocks, h, hd, out);
+    hipLaunchKernelGGL(k_finalize, dim3(1, bt.count), dim3(256), 0, s, z, npad, n, logdet_part, nt, part, nblocks, h,
+                       hd, out, bt.tab);
 }
 
 void launch_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, int k, hipStream_t s)

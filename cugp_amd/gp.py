@@ -251,6 +251,21 @@ class BCM:
         check(capi.lib().cugp_bcm_loglik_grad(self._h, C.byref(ll), ptr(g), ptr(per)))
         return ll.value, g, per
 
+    def loglik_grad_rows(self):
+        """-> [K, 4] rows (LL_k, gradient of -LL_k): what a multi-GPU BCM all-reduces."""
+        rows = np.empty((len(self.rows), 4))
+        check(capi.lib().cugp_bcm_loglik_grad_rows(self._h, ptr(rows)))
+        return rows
+
+    def expert(self, k):
+        """Borrowed view of expert k as a Covsum-like object (prediction, intermediates); owned by the BCM."""
+        h = C.c_void_p()
+        check(capi.lib().cugp_bcm_expert(self._h, int(k), C.byref(h)))
+        e = Covsum.__new__(Covsum)
+        e.n, e.d, e.device, e._h, e._data_key = self.rows[k], self.d, self.device, h, None
+        e.close = lambda: None                    # not ours to destroy
+        return e
+
     def get_BCM_loglikelihood(self):
         return self.loglik_grad()[0]
 

@@ -147,6 +147,9 @@ int cugp_bcm_set_expert_data(cugp_bcm *b, int k, const double *X, const double *
 int cugp_bcm_set_loghyper(cugp_bcm *b, const double hp[3]);      /* BCM::set_BCM_log_hyperparam BCM.cpp:123-130 */
 int cugp_bcm_get_loghyper(const cugp_bcm *b, double hp[3]);
 int cugp_bcm_loglik_grad(cugp_bcm *b, double *ll, double g[3], double *per_expert_ll);
+/* rows[k][4] = {LL_k, dLL_k/dtheta (as gradients of -LL)} per expert of this device: the payload a multi-device
+ * BCM sums across devices (the two gathers of cuda_scalingdist/cg_solver.cpp:72-213 in one buffer) */
+int cugp_bcm_loglik_grad_rows(cugp_bcm *b, double *rows);
 int cugp_bcm_predict_partial(cugp_bcm *b, const double *Xt, int nt, double *sum_prec, double *sum_prec_mean);
 int cugp_poe_finish(const double *sum_prec, const double *sum_prec_mean, int nt, double *mean, double *var);
 int cugp_bcm_predict(cugp_bcm *b, const double *Xt, int nt, double *mean, double *var); /* BCM.cpp:64-83 */

@@ -301,6 +301,38 @@ def test_graph_replay_matches_launch_by_launch(gp_mod, si128):
     assert np.array_equal(res[0], res[1])
 
 
+@pytest.mark.parametrize("K,n", [(4, 128), (3, 700), (5, 1000)])
+def test_grouped_experts_equal_single_experts(gp_mod, K, n):
+    """The experts of a BCM share launches (blockIdx.y = expert, common padded size): every expert's numbers
+    are bit-identical to the same expert evaluated alone, for equal and unequal row counts."""
+    X, y = synth(n, 6, seed=K)
+    b = gp_mod.BCM.split(X, y, K)
+    hp = np.array(HP_DENSE)
+    b.set_BCM_log_hyperparam(hp)
+    rows = b.loglik_grad_rows()
+    ll, g, per = b.loglik_grad()
+    part = n // K
+    Xt = X[:7] + 0.25
+    for k in range(K):
+        lo = k * part
+        hi = n if k == K - 1 else lo + part
+        one = gp_mod.Covsum(hi - lo, X.shape[1])
+        one.set_overlap(False)
+        one.set_data(X[lo:hi], y[lo:hi])
+        one.set_loghyperparam(hp)
+        l1, g1 = one.loglik_grad()
+        assert rows[k, 0] == l1 and np.array_equal(rows[k, 1:], g1) and per[k] == l1
+        m1, v1 = one.compute_test_means_and_variances(None, None, Xt)
+        mk, vk = b.expert(k).compute_test_means_and_variances(None, None, Xt)    # uses the grouped factorisation
+        assert np.array_equal(m1, mk) and np.array_equal(v1, vk)
+        one.close()
+    acc = 0.0
+    for k in range(K):                                   # the host sum runs in expert order (BCM.cpp:190-194)
+        acc = acc + rows[k, 0]
+    assert ll == acc
+    b.close()
+
+
 def test_bcm_cg_golden(gp_mod, si128, golden_si128):
     X, y = si128
     c = golden_si128["bcm"]["cg"]
