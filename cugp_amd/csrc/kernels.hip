@@ -984,18 +984,21 @@ __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, in
                                                       unsigned* __restrict__ tickets, int nfull,
                                                       const ExpertPtrs* __restrict__ bt)
 {
+    // batched: the EXPERT is the fast grid index, so the diagonal-block workgroups of all experts are
+    // dispatched before any tile product (the serial chain of every expert starts at launch)
+    const int bid = bt ? blockIdx.y : blockIdx.x;
     if (bt) {
-        const ExpertPtrs& e = bt[blockIdx.y];
+        const ExpertPtrs& e = bt[blockIdx.x];
         A = e.A; d16 = e.d16; d64 = e.d64; logdet_part = e.logdet; tickets = e.tickets;
     }
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ double red[TILE];
     __shared__ unsigned s_ticket;
-    if (blockIdx.x < NDIAGWG) {
+    if (bid < NDIAGWG) {
         // the factorisation's serial chain: win instruction issue over the product waves sharing the SIMD
         // (this launch's own tiles and the inverse blocks running on the other streams)
         __builtin_amdgcn_s_setprio(3);
-        diag_update_wave(A, ld, kb, blockIdx.x * 4 + (threadIdx.x >> 6));
+        diag_update_wave(A, ld, kb, bid * 4 + (threadIdx.x >> 6));
         // publish (cdna guide G16, counter form with write-through stores): every wave drains its sc1 stores,
         // workgroup barrier, then ONE lane draws the ticket (no agent release needed for sc1 stores)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1020,7 +1023,7 @@ __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, in
     // leave most of the chip idle for a whole tile time) as four 64x64 workgroups each.
     __builtin_amdgcn_s_setprio(1);                      // ahead of the inverse-block products (priority 0)
     const int k0 = kb * TILE;
-    const int x = blockIdx.x - NDIAGWG;
+    const int x = bid - NDIAGWG;
     if (x < nfull) {
         // Workgroups are dealt round-robin over the 8 XCDs (private L2 each): give every XCD one contiguous
         // run of the tile list, so neighbouring tiles (same panel rows) share an L2 (bijective for any count).
@@ -1392,8 +1395,9 @@ void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* d6
     const int ntl = tri_count(m) - 1;
     int nfull = ntl;
     if (ntl >= 512 && (ntl % 512) <= g_tune[TUNE_SYRK_REM_MAX]) nfull = ntl - ntl % 512;
-    hipLaunchKernelGGL(k_syrk_step, dim3(NDIAGWG + nfull + 4 * (ntl - nfull), bt.count), dim3(256), STEP_LDS, s, A, ld,
-                       kb, d16, d64, logdet_part, tickets, nfull, bt.tab);
+    const unsigned nwg = NDIAGWG + nfull + 4 * (ntl - nfull);
+    hipLaunchKernelGGL(k_syrk_step, bt.tab ? dim3(bt.count, nwg) : dim3(nwg), dim3(256), STEP_LDS, s, A, ld, kb, d16,
+                       d64, logdet_part, tickets, nfull, bt.tab);
 }
 
 void launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, int s, int step, hipStream_t st,
@@ -1409,7 +1413,7 @@ void launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, i
     if (tiles <= 0) return;
     // few 128-tiles cannot fill 512 workgroup slots: use 64x64 output tiles (4x the parallelism) there
     set_big_lds();
-    if (tiles <= g_tune[TUNE_TRTRI_WM2_MAX])
+    if (tiles * bt.count <= g_tune[TUNE_TRTRI_WM2_MAX])   // (a batched launch fills the chip with fewer tiles each)
         hipLaunchKernelGGL(k_trtri_level<2>, dim3(tiles * 4, bt.count), dim3(256), Geo<2>::LDS, st, L, T, U, ld, nt, s,
                            step, bt.tab);
     else
@@ -1448,7 +1452,7 @@ void launch_lauum(const double* U, double* Kinv, int ld, int a, int w, hipStream
 {
     set_big_lds();
     const int tiles = tri_count(a + w);
-    if (tiles <= g_tune[TUNE_LAUUM_WM2_MAX])
+    if (tiles * bt.count <= g_tune[TUNE_LAUUM_WM2_MAX])
         hipLaunchKernelGGL(k_lauum<2>, dim3(tiles * 4, bt.count), dim3(256), Geo<2>::LDS, s, U, Kinv, ld, a, w, bt.tab);
     else
         hipLaunchKernelGGL(k_lauum<4>, dim3(tiles, bt.count), dim3(256), GEMM_LDS, s, U, Kinv, ld, a, w, bt.tab);
