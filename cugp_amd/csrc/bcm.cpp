@@ -34,11 +34,19 @@ int cugp_bcm_create(int nexperts, const int* rows, int d, int device, cugp_bcm**
     if (!b) return CUGP_ERR_NOMEM;
     b->d = d;
     b->device = device;
-    int nmax = 0;
-    for (int k = 0; k < nexperts; k++) nmax = rows[k] > nmax ? rows[k] : nmax;
+    // Common padded size (identity padding) so that the experts can share launches -- unless their row counts
+    // differ by more than a tile or ~6 %: then padding the small ones would cost more than it gains.
+    int nmax = 0, nmin = rows[0];
+    for (int k = 0; k < nexperts; k++) {
+        if (rows[k] <= 0) { delete b; return CUGP_ERR_INVALID; }
+        nmax = rows[k] > nmax ? rows[k] : nmax;
+        nmin = rows[k] < nmin ? rows[k] : nmin;
+    }
+    const int tmax = (nmax + 127) / 128, tmin = (nmin + 127) / 128;
+    const int pad_to = (tmax - tmin <= (tmin / 16 > 1 ? tmin / 16 : 1)) ? nmax : 0;
     for (int k = 0; k < nexperts; k++) {
         cugp_gp* g = nullptr;
-        int rc = cugp_create_padded(rows[k], d, device, nmax, &g);   // common padded size (identity padding)
+        int rc = cugp_create_padded(rows[k], d, device, pad_to, &g);
         if (rc) { cugp_bcm_destroy(b); return rc; }
         // several experts on one device already fill each other's idle time; the extra streams only cost launches
         if (nexperts > 1) cugp_set_overlap(g, 0);

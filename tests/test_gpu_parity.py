@@ -333,6 +333,28 @@ def test_grouped_experts_equal_single_experts(gp_mod, K, n):
     b.close()
 
 
+def test_very_unequal_experts_keep_their_own_size(gp_mod):
+    """Experts whose row counts differ by more than a tile are not padded to a common size (they run from their
+    own streams instead of sharing launches); numbers equal the single experts' either way."""
+    X, y = synth(800, 5, seed=11)
+    parts = [(0, 100), (100, 800)]
+    b = gp_mod.BCM([hi - lo for lo, hi in parts], X.shape[1])
+    for k, (lo, hi) in enumerate(parts):
+        b.set_expert_data(k, X[lo:hi], y[lo:hi])
+    hp = np.array(HP_DENSE)
+    b.set_BCM_log_hyperparam(hp)
+    rows = b.loglik_grad_rows()
+    for k, (lo, hi) in enumerate(parts):
+        one = gp_mod.Covsum(hi - lo, X.shape[1])
+        one.set_overlap(False)
+        one.set_data(X[lo:hi], y[lo:hi])
+        one.set_loghyperparam(hp)
+        l1, g1 = one.loglik_grad()
+        assert rows[k, 0] == l1 and np.array_equal(rows[k, 1:], g1)
+        one.close()
+    b.close()
+
+
 def test_bcm_cg_golden(gp_mod, si128, golden_si128):
     X, y = si128
     c = golden_si128["bcm"]["cg"]
