@@ -92,6 +92,19 @@ __device__ __forceinline__ void tile_stage_mma(const char* __restrict__ cur, int
 // kbeg, kend multiples of BK.  All 256 threads must call (barriers inside).  WM (deduced from acc) is the
 // number of 16x16 MFMA tiles per wave per dimension: 4 -> 128x128 block, 2 -> 64x64 block.
 // LDS image per operand and stage: [k-pair plane (padded by 16 B)][row][2 doubles].
+#ifdef CUGP_TILE_STAMPS   // diagnostic build only (tools/gemm_k_bench.hip): where a tile's time goes
+__device__ unsigned long long g_tile_stamps[64];
+#define TILE_STAMP(i)                                                              \
+    do {                                                                           \
+        if (threadIdx.x == 0 && blockIdx.x == 200) {                               \
+            g_tile_stamps[i] = __builtin_readcyclecounter();                       \
+            g_tile_stamps[32 + i] = __builtin_amdgcn_s_memrealtime();              \
+        }                                                                          \
+    } while (0)
+#else
+#define TILE_STAMP(i)
+#endif
+
 template <bool NEGA, int WM>
 __device__ __forceinline__ void tile_nt(const double* __restrict__ Ag, int lda, const double* __restrict__ Bg,
                                         int ldb, int kbeg, int kend, d4 (&acc)[WM][WM], char* smem)
@@ -131,6 +144,7 @@ __device__ __forceinline__ void tile_nt(const double* __restrict__ Ag, int lda, 
         *(d2*)(smem + wb[q]) = rb[q];
     }
     __syncthreads();
+    TILE_STAMP(1);
 
     // two stages per trip so both LDS buffers are compile-time offsets (no address arithmetic in the loop)
 #define CUGP_STAGE(HALF, MORE, KNEXT)                                                              \

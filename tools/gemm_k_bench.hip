@@ -14,14 +14,32 @@ __global__ __launch_bounds__(256, 2) void k_gemm_persistent(const double* __rest
                                                             double* __restrict__ C, int n, int k, int mt, int ntiles)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    int it = 0;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x, it++) {
         const int ti = t % mt, tj = t / mt;
         d4 acc[4][4];
         acc_zero(acc);
+        if (it == 3) TILE_STAMP(0);
+#ifdef CUGP_TILE_STAMPS
+        if (threadIdx.x == 0 && (blockIdx.x == 200 || blockIdx.x == 7) && it < 10)
+            g_tile_stamps[(blockIdx.x == 7 ? 16 : 48) + it] = __builtin_amdgcn_s_memrealtime();
+#endif
         tile_nt<false>(A + (size_t)ti * TILE * k, k, B + (size_t)tj * TILE * k, k, 0, k, acc, smem);
+        if (it == 3) TILE_STAMP(2);
         tile_store(C + (size_t)ti * TILE * n + tj * TILE, n, acc, 1.0);
+        if (it == 3) TILE_STAMP(3);
+#ifdef CUGP_TILE_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (it == 3) TILE_STAMP(4);
+#endif
         __syncthreads();
+        if (it == 3) TILE_STAMP(5);
+        if (it == 4) TILE_STAMP(6);                       // (stamp 1 is overwritten by every tile: last one wins)
     }
+#ifdef CUGP_TILE_STAMPS
+    if (threadIdx.x == 0 && (blockIdx.x == 200 || blockIdx.x == 7) && it < 10)
+        g_tile_stamps[(blockIdx.x == 7 ? 16 : 48) + it] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 int main()
@@ -61,6 +79,21 @@ int main()
                 float ms2; hipEventElapsedTime(&ms2, e0, e1);
                 ms2 /= reps;
                 printf("   persistent x%d: %8.1f us %5.1f TF", slots, ms2 * 1e3, 2.0 * m * n * k / ms2 / 1e9);
+#ifdef CUGP_TILE_STAMPS
+                if (slots == 512) {
+                    unsigned long long st[64];
+                    hipMemcpyFromSymbol(st, HIP_SYMBOL(g_tile_stamps), sizeof(st));
+                    printf("\n      tile times (us) workgroup 7:");
+                    for (int i = 0; i < 8; i++) printf(" %.1f", (st[17 + i] - st[16 + i]) / 100.0);
+                    printf("   workgroup 200:");
+                    for (int i = 0; i < 8; i++) printf(" %.1f", (st[49 + i] - st[48 + i]) / 100.0);
+                    printf("\n      two tiles: %lld core cycles in %.2f us (100 MHz counter) = %.0f MHz",
+                           (long long)(st[6] - st[0]), (st[38] - st[32]) / 100.0, (st[6] - st[0]) / ((st[38] - st[32]) / 100.0));
+                    printf("\n      stamps (cycles from tile start): loop end %lld, stores issued %lld, stores done %lld, barrier %lld, next tile at %lld",
+                           (long long)(st[2] - st[0]), (long long)(st[3] - st[0]), (long long)(st[4] - st[0]),
+                           (long long)(st[5] - st[0]), (long long)(st[6] - st[0]));
+                }
+#endif
             }
         }
         printf("\n");
