@@ -181,7 +181,7 @@ int enqueue_inverse_block(cugp_gp* g, int a, int b, bool kinv, hipStream_t x, hi
     const int ld = g->npad, wb = b - a;
     const size_t off = (size_t)a * TILE * ld + (size_t)a * TILE;
     hipStream_t o = xs ? xs : x;
-    launch_trtri_diag(g->dA, ld, a, wb, g->d16, g->dT, g->dU, o, B(g));
+    launch_trtri_diag(g->dA, ld, a, wb, g->d64, g->dT, g->dU, o, B(g));
     for (int s = 1; s < wb; s *= 2) {
         launch_trtri_level(g->dA + off, g->dT + off, g->dU + off, ld, wb, s, 1, o, B(g));
         launch_trtri_level(g->dA + off, g->dT + off, g->dU + off, ld, wb, s, 2, o, B(g));
@@ -257,7 +257,7 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false)
         if ((rc = enqueue_inverse_block(g, 0, nt, true, m, nullptr, nullptr))) return rc;
     } else {
         // inverses of all diagonal factor blocks at once (off the factorisation's critical path)
-        launch_trtri_diag(g->dA, ld, 0, nt, g->d16, g->dT, g->dU, m, B(g));
+        launch_trtri_diag(g->dA, ld, 0, nt, g->d64, g->dT, g->dU, m, B(g));
     }
     HIPCHK(hipGetLastError());
     return CUGP_OK;

@@ -617,8 +617,7 @@ __global__ __launch_bounds__(256) void k_cross(const double* __restrict__ X, int
 // ------------------------------------------------------------------------------------------
 // diagonal block: 128x128 Cholesky in LDS (one workgroup), 16-wide inner blocks
 // ------------------------------------------------------------------------------------------
-constexpr int PLD = TILE + 1;                      // padded LDS row stride (doubles) of k_trtri_diag
-constexpr int TRTRI_LDS = TILE * PLD * 8 + (TILE - 16) * 17 * 8;
+constexpr int TRTRI_LDS = NLT * MTS * 8;             // the 36 lower micro tiles
 
 // ---- helpers for the diagonal block ------------------------------------------------------
 
@@ -1063,60 +1062,60 @@ __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, in
     }
 }
 
-// inverse of a 128x128 diagonal factor block from its 16x16 diagonal inverses (blocked, right to left);
-// writes T (lower, zeros above) and U = T^T (upper, zeros below).  blockIdx.x = block offset from kb.
+// inverse of a 128x128 diagonal factor block from the two 64x64 inverses potf2 left in d64 (one doubling
+// step, T10 = -T11 (L10 T00), on 16x16 micro tiles: wave = micro-tile column of T10); writes T (lower, zeros
+// above) and U = T^T (upper, zeros below).  blockIdx.x = block offset from kb.  ~6 us (the blocked
+// substitution from the 16x16 inverses it replaces took 92 us -- 10 % of a 1500-row evaluation).
 __global__ __launch_bounds__(256) void k_trtri_diag(const double* __restrict__ A, int ld, int kb,
-                                                    const double* __restrict__ d16, double* __restrict__ T,
+                                                    const double* __restrict__ d64, double* __restrict__ T,
                                                     double* __restrict__ U, const ExpertPtrs* __restrict__ bt)
 {
-    if (bt) { A = bt[blockIdx.y].A; d16 = bt[blockIdx.y].d16; T = bt[blockIdx.y].T; U = bt[blockIdx.y].U; }
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    double* ytmp = sm + TILE * PLD;                             // [(TILE-16)][17]
-    const int t = threadIdx.x;
+    if (bt) { A = bt[blockIdx.y].A; d64 = bt[blockIdx.y].d64; T = bt[blockIdx.y].T; U = bt[blockIdx.y].U; }
+    extern __shared__ __attribute__((aligned(16))) double sm[];       // 36 lower micro tiles, as potf2_body
+    const int t = threadIdx.x, wave = t >> 6;
     const int b = kb + blockIdx.x;
     const double* Ab = A + (size_t)b * TILE * ld + b * TILE;
-    const double* db = d16 + (size_t)b * 8 * 256;
-
-    for (int e = t; e < TILE * TILE; e += 256) {
-        int r = e >> 7, c = e & 127;
-        sm[r * PLD + c] = (c <= r) ? Ab[(size_t)r * ld + c] : 0.0;
+    const double* T00 = d64 + (size_t)b * 8192;
+    const double* T11 = T00 + 4096;
+    {
+        const int r = t >> 4, c = t & 15;
+        for (int bi = 0; bi < NMT; bi++)
+            for (int bj = 0; bj <= bi; bj++) {
+                double v;
+                if (bi < 4) v = T00[(bi * MT + r) * 64 + bj * MT + c];
+                else if (bj >= 4) v = T11[((bi - 4) * MT + r) * 64 + (bj - 4) * MT + c];
+                else v = Ab[(size_t)(bi * MT + r) * ld + bj * MT + c];            // L10
+                sm[mt_off(bi, bj) + r * (MT + 1) + c] = v;
+            }
     }
     __syncthreads();
-    for (int jb = TILE / 16 - 1; jb >= 0; jb--) {
-        const int j0 = jb * 16;
-        const int m = TILE - j0 - 16;
-        const double* dj = db + jb * 256;
-        if (m > 0) {
-            // Y[i][c] = sum_{k=j0+16..i} T[i][k] * L[k][j0+c]
-            for (int e = t; e < m * 16; e += 256) {
-                const int ii = e >> 4, c = e & 15;
-                const int i = j0 + 16 + ii;
-                double s = 0.0;
-                for (int k = j0 + 16; k <= i; k++) s += sm[i * PLD + k] * sm[k * PLD + j0 + c];
-                ytmp[ii * 17 + c] = s;
-            }
-            __syncthreads();
-            // T21[i][c] = -sum_{k>=c} Y[i][k] * D[k][c]
-            for (int e = t; e < m * 16; e += 256) {
-                const int ii = e >> 4, c = e & 15;
-                double s = 0.0;
-                for (int k = c; k < 16; k++) s += ytmp[ii * 17 + k] * dj[k * 16 + c];
-                sm[(j0 + 16 + ii) * PLD + j0 + c] = -s;
-            }
+    {
+        const int bj = wave;                                 // my micro-tile column of T10
+        const d4 zero4 = (d4){0.0, 0.0, 0.0, 0.0};
+        d4 w[4];                                             // W(4 + q, bj) = sum_{jp >= bj} L10(4 + q, jp) T00(jp, bj)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            w[q] = zero4;
+            for (int jp = bj; jp < 4; jp++) w[q] = micro_mma_nn(sm + mt_off(4 + q, jp), sm + mt_off(jp, bj), w[q]);
         }
-        __syncthreads();
-        if (t < 256) {
-            const int i = t >> 4, c = t & 15;
-            sm[(j0 + i) * PLD + j0 + c] = (c <= i) ? dj[i * 16 + c] : 0.0;
+        __syncthreads();                                     // every wave has read its L10 tiles
+#pragma unroll
+        for (int q = 0; q < 4; q++) {                        // T10(4 + q, bj) = -sum_{k <= q} T11(4 + q, 4 + k) W(4 + k, bj)
+            d4 x = zero4;
+#pragma unroll
+            for (int k = 0; k <= q; k++) x = micro_mma_acc_b(sm + mt_off(4 + q, 4 + k), w[k], x);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            micro_store(sm + mt_off(4 + q, bj), x);
         }
-        __syncthreads();
     }
+    __syncthreads();
     double* Tb = T + (size_t)b * TILE * ld + b * TILE;
     double* Ub = U + (size_t)b * TILE * ld + b * TILE;
     for (int e = t; e < TILE * TILE; e += 256) {
-        int r = e >> 7, c = e & 127;
-        Tb[(size_t)r * ld + c] = sm[r * PLD + c];          // upper part already zero
-        Ub[(size_t)r * ld + c] = sm[c * PLD + r];          // transpose
+        const int r = e >> 7, c = e & 127, br = r >> 4, bc = c >> 4;
+        // T(r,c) lives in micro tile (br,bc) when bc <= br (diagonal micro tiles are zero above their diagonal)
+        Tb[(size_t)r * ld + c] = bc <= br ? sm[mt_off(br, bc) + (r & 15) * (MT + 1) + (c & 15)] : 0.0;
+        Ub[(size_t)r * ld + c] = br <= bc ? sm[mt_off(bc, br) + (c & 15) * (MT + 1) + (r & 15)] : 0.0;   // T(c,r)
     }
 }
 
@@ -1391,11 +1390,11 @@ void launch_trsm_inv64(double* A, const double* d64, int ld, int kb, int nt, hip
     hipLaunchKernelGGL(k_trsm_inv64, dim3(nstrips, bt.count), dim3(256), 0, s, A, d64, ld, kb, bt.tab);
 }
 
-void launch_trtri_diag(const double* A, int ld, int kb, int nblocks, const double* d16, double* T, double* U,
+void launch_trtri_diag(const double* A, int ld, int kb, int nblocks, const double* d64, double* T, double* U,
                        hipStream_t s, Batch bt)
 {
     set_big_lds();
-    hipLaunchKernelGGL(k_trtri_diag, dim3(nblocks, bt.count), dim3(256), TRTRI_LDS, s, A, ld, kb, d16, T, U, bt.tab);
+    hipLaunchKernelGGL(k_trtri_diag, dim3(nblocks, bt.count), dim3(256), TRTRI_LDS, s, A, ld, kb, d64, T, U, bt.tab);
 }
 
 void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* d64, double* logdet_part,
