@@ -188,6 +188,23 @@ def test_live_oracle(gp_mod, oracle, n, d, nt):
     assert np.allclose(m, mo, rtol=1e-8, atol=1e-8) and np.allclose(v, vo, rtol=1e-8, atol=1e-8)
 
 
+@pytest.mark.parametrize("n,d", [(2, 2), (127, 4), (129, 10), (257, 3), (1025, 10), (1300, 6), (2049, 10)])
+def test_size_sweep_vs_oracle(gp_mod, oracle, n, d):
+    """Tile-boundary sizes against the CPU oracle: 1..17 tiles, so every hand-over pattern of the inverse blocks
+    (none, blocks of 2 with a ragged last one) and both the replayed and the launch-by-launch form occur."""
+    X, y = synth(n, d=d, seed=3 * n + d, scale=4.0)
+    hp = [0.9, 0.2, -1.0]
+    llo, gro = oracle.loglik_grad(X, y, hp)
+    for overlap in (True, False):
+        g = gp_mod.Covsum(n, d)
+        g.set_overlap(overlap)
+        g.set_loghyperparam(hp)
+        ll, gr = g.loglik_grad(X, y)
+        assert ll_close(ll, llo) and vec_close(gr, gro), (n, overlap, ll, llo, gr, gro)
+        assert ll_close(g.compute_loglikelihood(), llo)
+        g.close()
+
+
 def test_big_golden_4096(gp_mod, sine):
     """config 2 (sine_dataset_4096_10, log-lik matches CPU to 1e-8) -- only when the fixture exists."""
     import json, os
