@@ -88,6 +88,8 @@ struct cugp_gp {
     bool pending = false, pending_grad = false;
     bool joined = true;            // no inverse blocks outstanding on `aux`
     const GroupCtx* grp = nullptr;  // non-null only inside cugp_group_eval
+    double* pred_buf = nullptr;     // prediction scratch (test inputs, cross-covariance, its product with L^-T, results)
+    size_t pred_cap = 0;            // ... in doubles, grow-only
     bool overlap = true;           // hand inverse blocks to the other streams while the factorisation runs
     // a single-stream evaluation is captured once as a HIP graph and replayed: one launch call instead of
     // ~60 (1500 rows) -- with 16 experts on a GPU the host's launch rate was the bound, not the device
@@ -469,6 +471,7 @@ int cugp_destroy(cugp_gp* g)
     for (double* p : bufs)
         if (p) (void)hipFree(p);
     if (g->dtickets) (void)hipFree(g->dtickets);
+    if (g->pred_buf) (void)hipFree(g->pred_buf);
     if (g->hout) (void)hipHostFree(g->hout);
     if (g->hhs) (void)hipHostFree(g->hhs);
     if (g->dhs) (void)hipFree(g->dhs);
@@ -619,12 +622,24 @@ static int predict_device(cugp_gp* g, const double* Xt, int nt, double** dmean_o
     if ((rc = cugp_loglik_grad(g, nullptr, nullptr))) return rc;     // factor, T, alpha for the current hp
     const int ntpad = ((nt + TILE - 1) / TILE) * TILE;
     const HyperScalars h = scalars(g);
-    double *dXt = nullptr, *dKs = nullptr, *dW = nullptr, *dm = nullptr, *dv = nullptr;
-    HIPCHK(hipMalloc((void**)&dXt, (size_t)nt * g->d * sizeof(double))); to_free.push_back(dXt);
-    HIPCHK(hipMalloc((void**)&dKs, (size_t)ntpad * g->npad * sizeof(double))); to_free.push_back(dKs);
-    HIPCHK(hipMalloc((void**)&dW, (size_t)ntpad * g->npad * sizeof(double))); to_free.push_back(dW);
-    HIPCHK(hipMalloc((void**)&dm, (size_t)nt * sizeof(double))); to_free.push_back(dm);
-    HIPCHK(hipMalloc((void**)&dv, (size_t)nt * sizeof(double))); to_free.push_back(dv);
+    // prediction scratch lives with the handle and only grows (the allocations cost more than the kernels
+    // for a few hundred test points)
+    (void)to_free;
+    const size_t nxt = (((size_t)nt * g->d + 15) / 16) * 16, nks = (size_t)ntpad * g->npad, nv = (size_t)ntpad;
+    const size_t need = nxt + 2 * nks + 2 * nv;
+    if (need > g->pred_cap) {
+        HIPCHK(hipStreamSynchronize(g->stream));
+        if (g->pred_buf) (void)hipFree(g->pred_buf);
+        g->pred_buf = nullptr;
+        g->pred_cap = 0;
+        HIPCHK(hipMalloc((void**)&g->pred_buf, need * sizeof(double)));
+        g->pred_cap = need;
+    }
+    double* dXt = g->pred_buf;
+    double* dKs = dXt + nxt;
+    double* dW = dKs + nks;
+    double* dm = dW + nks;
+    double* dv = dm + nv;
     HIPCHK(hipMemcpyAsync(dXt, Xt, (size_t)nt * g->d * sizeof(double), hipMemcpyHostToDevice, g->stream));
     launch_kcross(g->dX, g->n, g->d, g->npad, dXt, nt, ntpad, h, dKs, g->stream);
     launch_predict_gemm(dKs, g->dT, dW, g->npad, ntpad / TILE, g->nt, g->stream);
