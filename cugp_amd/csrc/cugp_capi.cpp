@@ -165,12 +165,13 @@ Batch B(const cugp_gp* g) { return g->grp ? g->grp->bt : Batch{}; }
 
 unsigned g_cfg_epoch = 1;          // bumped by cugp_set_tuning: captured graphs carry launch shapes
 
-// block rows per hand-over to the other streams: about an eighth of the matrix (A/B runs at 12..64 tiles),
-// or as tuned; 0 = no hand-over (everything on the main stream after the factorisation)
+// block rows per hand-over to the other streams: about a sixteenth of the matrix, at least 2 tiles (interleaved
+// A/B at 16, 32, 64 and 79 tiles: 2, 2-3, 4, 5 were the best), or as tuned; 0 = no hand-over (everything on the
+// main stream after the factorisation)
 int pipe_block(const cugp_gp* g, bool with_inverse)
 {
     int w = (with_inverse && g->overlap) ? g_tune[TUNE_PIPE_BLOCK] : 0;
-    if (w < 0) w = g->nt < 16 ? 2 : (g->nt + 4) / 8;
+    if (w < 0) w = (g->nt + 8) / 16 > 2 ? (g->nt + 8) / 16 : 2;
     return w >= g->nt ? 0 : w;
 }
 

@@ -11,7 +11,7 @@ constexpr int TILE = 128;          // tile edge of every fp64 MFMA product and o
 enum { TUNE_LAUUM_WM2_MAX = 0,   // K^-1 product: use 64x64 tiles when there are at most this many 128-tiles
        TUNE_TRTRI_WM2_MAX = 1,   // inverse level: same rule
        TUNE_SYRK_REM_MAX = 2,    // trailing update: split the last partial round into 64x64 quarters when it has at most this many tiles
-       TUNE_PIPE_BLOCK = 3,      // inverse rows (tiles) handed to the other streams at a time while the factorisation runs; 0 = after it, < 0 = about nt/8
+       TUNE_PIPE_BLOCK = 3,      // inverse rows (tiles) handed to the other streams at a time while the factorisation runs; 0 = after it, < 0 = about nt/16
        TUNE_BORDER_WM2_MAX = 4,  // bordering step 1 (uniform K): 64x64 tiles when there are at most this many 128-tiles
        TUNE_GRAPHS = 5,          // replay single-stream evaluations as a captured HIP graph (1) or launch by launch (0)
        TUNE_COUNT = 6 };
