@@ -32,6 +32,7 @@ SIGNATURES = {
     "cugp_last_error": (C.c_char_p, []),
     "cugp_device_count": (C.c_int, [_ip]),
     "cugp_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "cugp_create_padded": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "cugp_destroy": (C.c_int, [C.c_void_p]),
     "cugp_dims": (C.c_int, [C.c_void_p, _ip, _ip, _ip]),
     "cugp_set_overlap": (C.c_int, [C.c_void_p, C.c_int]),

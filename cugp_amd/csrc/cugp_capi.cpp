@@ -66,6 +66,7 @@ struct GroupCtx {
     unsigned* tickets = nullptr;    // the experts' step tickets, contiguous [k][nt]
     double* dout = nullptr;         // results [k][8] on the device ...
     double* hout = nullptr;         // ... and pinned
+    bool overlap = false;           // hand the group's inverse blocks to the lead expert's other streams
 };
 
 struct cugp_gp {
@@ -170,7 +171,8 @@ unsigned g_cfg_epoch = 1;          // bumped by cugp_set_tuning: captured graphs
 // main stream after the factorisation)
 int pipe_block(const cugp_gp* g, bool with_inverse)
 {
-    int w = (with_inverse && g->overlap) ? g_tune[TUNE_PIPE_BLOCK] : 0;
+    const bool overlap = g->grp ? g->grp->overlap : g->overlap;
+    int w = (with_inverse && overlap) ? g_tune[TUNE_PIPE_BLOCK] : 0;
     if (w < 0) w = (g->nt + 8) / 16 > 2 ? (g->nt + 8) / 16 : 2;
     return w >= g->nt ? 0 : w;
 }
@@ -186,17 +188,17 @@ int enqueue_inverse_block(cugp_gp* g, int a, int b, bool kinv, hipStream_t x, hi
     hipStream_t o = xs ? xs : x;
     launch_trtri_diag(g->dA, ld, a, wb, g->d64, g->dT, g->dU, o, B(g));
     for (int s = 1; s < wb; s *= 2) {
-        launch_trtri_level(g->dA + off, g->dT + off, g->dU + off, ld, wb, s, 1, o, B(g));
-        launch_trtri_level(g->dA + off, g->dT + off, g->dU + off, ld, wb, s, 2, o, B(g));
+        launch_trtri_level(g->dA, g->dT, g->dU, ld, wb, s, 1, o, B(g), off);
+        launch_trtri_level(g->dA, g->dT, g->dU, ld, wb, s, 2, o, B(g), off);
     }
     if (xs) {
         HIPCHK(hipEventRecord(own_done, xs));
         HIPCHK(hipStreamWaitEvent(x, own_done, 0));
     }
     // rows [a, b): their Wt was accumulated chunk by chunk while the earlier blocks became final
-    if (a > 0) launch_trtri_border2(g->dA, g->dT, g->dU, ld, a, wb, x);
+    if (a > 0) launch_trtri_border2(g->dA, g->dT, g->dU, ld, a, wb, x, B(g));
     // ... and these rows, now final, go into the Wt of every row below them
-    if (b < g->nt) launch_trtri_border1(g->dA, g->dT, g->dU, ld, b, g->nt - b, a, b, x);
+    if (b < g->nt) launch_trtri_border1(g->dA, g->dT, g->dU, ld, b, g->nt - b, a, b, x, B(g));
     if (kinv) launch_lauum(g->dU, g->dKinv, ld, a, wb, x, B(g));
     return CUGP_OK;
 }
@@ -1101,7 +1103,7 @@ int cugp_group_eval(cugp_group* gr, int want_grad, double* ll, double* g)
     int rc;
     if (nt > GROUP_MAX_TILES) return CUGP_ERR_INVALID;
     for (cugp_gp* e : gr->experts) {
-        if (!e->have_data || e->prof != 0 || pipe_block(e, want_grad != 0) != 0) return CUGP_ERR_INVALID;
+        if (!e->have_data || e->prof != 0 || pipe_block(e, want_grad != 0) != 0) return CUGP_ERR_INVALID;   // (experts of a BCM have their own overlap off)
         if (e->hp[0] != lead->hp[0] || e->hp[1] != lead->hp[1] || e->hp[2] != lead->hp[2]) return CUGP_ERR_INVALID;
     }
     if ((rc = use_device(lead))) return rc;
@@ -1126,9 +1128,11 @@ int cugp_group_eval(cugp_group* gr, int want_grad, double* ll, double* g)
     }
     for (cugp_gp* e : gr->experts) e->factor_valid = e->inverse_valid = false;
     *lead->hhs = scalars(lead);
+    gr->ctx.overlap = g_tune[TUNE_GROUP_OVERLAP] != 0;
     lead->grp = &gr->ctx;
     const int gi = want_grad ? 1 : 0;
-    if (g_tune[TUNE_GRAPHS] != 0 && nt <= GRAPH_MAX_TILES) {
+    // (with the hand-over the sequence spans three streams: enqueued launch by launch, not replayed)
+    if (g_tune[TUNE_GRAPHS] != 0 && nt <= GRAPH_MAX_TILES && pipe_block(lead, want_grad != 0) == 0) {
         if (!gr->gexec[gi] || gr->gepoch[gi] != g_cfg_epoch) {
             if (gr->gexec[gi]) (void)hipGraphExecDestroy(gr->gexec[gi]);
             gr->gexec[gi] = nullptr;

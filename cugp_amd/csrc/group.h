@@ -8,10 +8,6 @@ struct cugp_group;
 
 extern "C" {
 
-// like cugp_create, with the matrices padded to at least npad_min rows (a multiple of 128): the experts of a
-// BCM get a common padded size so that they can share launches (identity padding leaves every result unchanged)
-int cugp_create_padded(int n, int d, int device, int npad_min, cugp_gp** out);
-
 // experts must live on one device and agree in padded size and dimension (else CUGP_ERR_INVALID)
 int cugp_group_create(cugp_gp* const* experts, int k, cugp_group** out);
 void cugp_group_destroy(cugp_group* gr);

@@ -14,7 +14,8 @@ enum { TUNE_LAUUM_WM2_MAX = 0,   // K^-1 product: use 64x64 tiles when there are
        TUNE_PIPE_BLOCK = 3,      // inverse rows (tiles) handed to the other streams at a time while the factorisation runs; 0 = after it, < 0 = about nt/16
        TUNE_BORDER_WM2_MAX = 4,  // bordering step 1 (uniform K): 64x64 tiles when there are at most this many 128-tiles
        TUNE_GRAPHS = 5,          // replay single-stream evaluations as a captured HIP graph (1) or launch by launch (0)
-       TUNE_COUNT = 6 };
+       TUNE_GROUP_OVERLAP = 6,   // grouped experts: inverse blocks on the other streams beside the factorisation (1) or after it (0)
+       TUNE_COUNT = 7 };
 extern int g_tune[TUNE_COUNT];
 
 struct HyperScalars;
@@ -61,13 +62,15 @@ void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* d6
                       unsigned* tickets, hipStream_t s, Batch bt = {});
 
 // ---- triangular inverse by recursive doubling (N7) and K^-1 = U U^T (N8) ----
+// off: element offset of the diagonal sub-matrix (nt tiles) the level works on inside L, T, U
 void launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, int s, int step, hipStream_t st,
-                        Batch bt = {});
+                        Batch bt = {}, size_t off = 0);
 // bordering step 1, one k chunk: Wt(tj < c1, ti in [ra, ra+rw)) (+)= sum_{k in [max(tj,c0), c1)} U[tj][k] L[ti][k]
 void launch_trtri_border1(const double* L, double* T, double* U, int ld, int ra, int rw, int c0, int c1,
-                          hipStream_t st);
+                          hipStream_t st, Batch bt = {});
 // bordering step 2: rows [a, a+w) of the inverse from their finished Wt and the block's own inverse
-void launch_trtri_border2(const double* L, double* T, double* U, int ld, int a, int w, hipStream_t st);
+void launch_trtri_border2(const double* L, double* T, double* U, int ld, int a, int w, hipStream_t st,
+                          Batch bt = {});
 // Kinv(lower tiles < a+w) (+)= contribution of inverse rows [a, a+w); a = 0, w = nt: the whole product
 void launch_lauum(const double* U, double* Kinv, int ld, int a, int w, hipStream_t s, Batch bt = {});
 

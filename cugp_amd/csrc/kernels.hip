@@ -340,9 +340,11 @@ __device__ __forceinline__ void trtri_tile(const double* __restrict__ L, double*
 template <int WM>
 __global__ __launch_bounds__(256, 2) void k_trtri_level(const double* __restrict__ L, double* __restrict__ T,
                                                         double* __restrict__ U, int ld, int nt, int s, int step,
-                                                        const ExpertPtrs* __restrict__ bt)
+                                                        size_t off, const ExpertPtrs* __restrict__ bt)
 {
+    // off: element offset of the diagonal sub-matrix the level works on (a block of inverse rows)
     if (bt) { L = bt[blockIdx.y].A; T = bt[blockIdx.y].T; U = bt[blockIdx.y].U; }
+    L += off; T += off; U += off;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SUB = 4 / WM;
     const int blk = blockIdx.x / (SUB * SUB), sub = blockIdx.x % (SUB * SUB);
@@ -370,8 +372,9 @@ __global__ __launch_bounds__(256, 2) void k_trtri_level(const double* __restrict
 template <int WM>
 __global__ __launch_bounds__(256, 2) void k_trtri_border(const double* __restrict__ L, double* __restrict__ T,
                                                          double* __restrict__ U, int ld, int a, int w, int step,
-                                                         int c0, int c1)
+                                                         int c0, int c1, const ExpertPtrs* __restrict__ bt)
 {
+    if (bt) { L = bt[blockIdx.y].A; T = bt[blockIdx.y].T; U = bt[blockIdx.y].U; }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SUB = 4 / WM;
     const int blk = blockIdx.x / (SUB * SUB), sub = blockIdx.x % (SUB * SUB);
@@ -1337,7 +1340,7 @@ __global__ __launch_bounds__(256) void k_predict_finish(const double* __restrict
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-int g_tune[TUNE_COUNT] = {768, 1200, 384, -1, 511, 1};   // defaults chosen by interleaved A/B runs (tools/ab.py)
+int g_tune[TUNE_COUNT] = {768, 1200, 384, -1, 511, 1, 1};   // defaults chosen by interleaved A/B runs (tools/ab.py)
 
 static inline int tri_count(int n) { return n * (n + 1) / 2; }
 
@@ -1414,7 +1417,7 @@ void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* d6
 }
 
 void launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, int s, int step, hipStream_t st,
-                        Batch bt)
+                        Batch bt, size_t off)
 {
     // pairs p = 0.. : A = [2ps, 2ps+s), B = [2ps+s, min(2ps+2s, nt)); count tiles |A| x |B|
     int tiles = 0;
@@ -1428,37 +1431,40 @@ void launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, i
     set_big_lds();
     if (tiles * bt.count <= g_tune[TUNE_TRTRI_WM2_MAX])   // (a batched launch fills the chip with fewer tiles each)
         hipLaunchKernelGGL(k_trtri_level<2>, dim3(tiles * 4, bt.count), dim3(256), Geo<2>::LDS, st, L, T, U, ld, nt, s,
-                           step, bt.tab);
+                           step, off, bt.tab);
     else
         hipLaunchKernelGGL(k_trtri_level<4>, dim3(tiles, bt.count), dim3(256), GEMM_LDS, st, L, T, U, ld, nt, s, step,
-                           bt.tab);
+                           off, bt.tab);
 }
 
 // step 1 of the bordering, spread over time: add the k tiles [c0, c1) (a block of inverse rows that just
 // became final) to Wt(tj < c1, ti in [ra, ra+rw)) for ALL rows below the block
 void launch_trtri_border1(const double* L, double* T, double* U, int ld, int ra, int rw, int c0, int c1,
-                          hipStream_t st)
+                          hipStream_t st, Batch bt)
 {
     const int tiles = c1 * rw;
     if (tiles <= 0) return;
     set_big_lds();
-    if (tiles <= g_tune[TUNE_BORDER_WM2_MAX])
-        hipLaunchKernelGGL(k_trtri_border<2>, dim3(tiles * 4), dim3(256), Geo<2>::LDS, st, L, T, U, ld, ra, rw, 1, c0,
-                           c1);
+    if (tiles * bt.count <= g_tune[TUNE_BORDER_WM2_MAX])
+        hipLaunchKernelGGL(k_trtri_border<2>, dim3(tiles * 4, bt.count), dim3(256), Geo<2>::LDS, st, L, T, U, ld, ra, rw,
+                           1, c0, c1, bt.tab);
     else
-        hipLaunchKernelGGL(k_trtri_border<4>, dim3(tiles), dim3(256), GEMM_LDS, st, L, T, U, ld, ra, rw, 1, c0, c1);
+        hipLaunchKernelGGL(k_trtri_border<4>, dim3(tiles, bt.count), dim3(256), GEMM_LDS, st, L, T, U, ld, ra, rw, 1, c0,
+                           c1, bt.tab);
 }
 
 // step 2: rows [a, a+w) of the inverse from their finished Wt and the block's own inverse
-void launch_trtri_border2(const double* L, double* T, double* U, int ld, int a, int w, hipStream_t st)
+void launch_trtri_border2(const double* L, double* T, double* U, int ld, int a, int w, hipStream_t st, Batch bt)
 {
     const int tiles = a * w;
     if (tiles <= 0) return;
     set_big_lds();
-    if (tiles <= g_tune[TUNE_TRTRI_WM2_MAX])
-        hipLaunchKernelGGL(k_trtri_border<2>, dim3(tiles * 4), dim3(256), Geo<2>::LDS, st, L, T, U, ld, a, w, 2, 0, 0);
+    if (tiles * bt.count <= g_tune[TUNE_TRTRI_WM2_MAX])
+        hipLaunchKernelGGL(k_trtri_border<2>, dim3(tiles * 4, bt.count), dim3(256), Geo<2>::LDS, st, L, T, U, ld, a, w, 2,
+                           0, 0, bt.tab);
     else
-        hipLaunchKernelGGL(k_trtri_border<4>, dim3(tiles), dim3(256), GEMM_LDS, st, L, T, U, ld, a, w, 2, 0, 0);
+        hipLaunchKernelGGL(k_trtri_border<4>, dim3(tiles, bt.count), dim3(256), GEMM_LDS, st, L, T, U, ld, a, w, 2, 0, 0,
+                           bt.tab);
 }
 
 void launch_lauum(const double* U, double* Kinv, int ld, int a, int w, hipStream_t s, Batch bt)

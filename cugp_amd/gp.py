@@ -16,10 +16,10 @@ class Covsum:
     """One GP expert on one GPU.  Covsum(n, d) as covkernel.cpp:14-37; X, y are given per call as in
     the reference and uploaded when they change (identity of the arrays is the cache key)."""
 
-    def __init__(self, n, d, device=0):
+    def __init__(self, n, d, device=0, npad_min=0):
         self.n, self.d, self.device = int(n), int(d), int(device)
         self._h = C.c_void_p()
-        check(capi.lib().cugp_create(self.n, self.d, self.device, C.byref(self._h)))
+        check(capi.lib().cugp_create_padded(self.n, self.d, self.device, int(npad_min), C.byref(self._h)))
         self._data_key = None
 
     # -- lifetime --

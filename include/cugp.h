@@ -44,6 +44,10 @@ int cugp_device_count(int *count);
 /* ---- lifetime: Covsum::Covsum(n,d) covkernel.cpp:14-37 ; setup(numtrain,dim) cuda_scalingdist/cuda_gp.cu:587 ;
  *      ~Covsum covkernel.cpp:39-61 ; destruct_cublas_cusoler cuda_gp.cu ---- */
 int cugp_create(int n, int d, int device, cugp_gp **out);
+/* the same with the matrices padded (by identity rows: no result changes) to at least npad_min rows -- the
+ * experts of a BCM get one common padded size so that they can share launches (distributed_gp/BCM.cpp:85-110
+ * gives the last expert the remainder rows) */
+int cugp_create_padded(int n, int d, int device, int npad_min, cugp_gp **out);
 int cugp_destroy(cugp_gp *gp);
 int cugp_dims(const cugp_gp *gp, int *n, int *d, int *npad);
 /* A gradient evaluation builds L^-1 and K^-1 block row by block row on two further streams while the
