@@ -47,8 +47,6 @@ int fail(int code, const char* what, hipError_t e = hipSuccess)
 constexpr int NPHASE = 6;
 constexpr int MAX_KEV = 4096;   // per-launch event pairs kept between resets
 constexpr int GRAPH_MAX_TILES = 24;   // evaluations up to 3072 rows are replayed as captured graphs
-constexpr int GROUP_MAX_TILES = 32;   // experts up to 4096 rows share launches; larger ones fill the chip better
-                                      // from their own streams (4 x 6000 rows: 18.3 ms on streams, 19.3 ms grouped)
 constexpr int PROF_STRIDE = 8;  // profiling level 2 times every 8th trailing-update launch, rotating
 
 // One hardware queue per stream up to 16 (the runtime default is 4): the experts of a BCM on one device each
@@ -1101,7 +1099,7 @@ int cugp_group_eval(cugp_group* gr, int want_grad, double* ll, double* g)
     cugp_gp* lead = gr->experts[0];
     const int k = (int)gr->experts.size(), nt = lead->nt;
     int rc;
-    if (nt > GROUP_MAX_TILES) return CUGP_ERR_INVALID;
+    if (nt > g_tune[TUNE_GROUP_MAX_TILES]) return CUGP_ERR_INVALID;
     for (cugp_gp* e : gr->experts) {
         if (!e->have_data || e->prof != 0 || pipe_block(e, want_grad != 0) != 0) return CUGP_ERR_INVALID;   // (experts of a BCM have their own overlap off)
         if (e->hp[0] != lead->hp[0] || e->hp[1] != lead->hp[1] || e->hp[2] != lead->hp[2]) return CUGP_ERR_INVALID;

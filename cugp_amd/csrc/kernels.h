@@ -15,7 +15,8 @@ enum { TUNE_LAUUM_WM2_MAX = 0,   // K^-1 product: use 64x64 tiles when there are
        TUNE_BORDER_WM2_MAX = 4,  // bordering step 1 (uniform K): 64x64 tiles when there are at most this many 128-tiles
        TUNE_GRAPHS = 5,          // replay single-stream evaluations as a captured HIP graph (1) or launch by launch (0)
        TUNE_GROUP_OVERLAP = 6,   // grouped experts: inverse blocks on the other streams beside the factorisation (1) or after it (0)
-       TUNE_COUNT = 7 };
+       TUNE_GROUP_MAX_TILES = 7, // experts up to this many tiles share launches (default: all; with the inverse beside the factorisation grouping won at every size tried: 4 x 6000 rows 18.9 -> 18.3 ms, 2 x 8192 rows 23.6 -> 21.9 ms)
+       TUNE_COUNT = 8 };
 extern int g_tune[TUNE_COUNT];
 
 struct HyperScalars;

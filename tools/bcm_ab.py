@@ -8,9 +8,9 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import cugp_amd.gp as gp
 from cugp_amd import capi
 from conftest import synth
-DEFAULT = {0: 768, 1: 1200, 2: 384, 3: -1, 4: 511, 5: 1, 6: 1}
+DEFAULT = {0: 768, 1: 1200, 2: 384, 3: -1, 4: 511, 5: 1, 6: 1, 7: 1048576}
 variants = [dict((int(k), int(v)) for k, v in (kv.split("=") for kv in a.split(","))) for a in sys.argv[1:]] or [{}]
-for K, rows in ((16, 1500), (2, 1500), (4, 6000), (1, 1500), (1, 256)):
+for K, rows in ((16, 1500), (2, 1500), (4, 6000), (2, 8192), (8, 3000), (1, 1500), (1, 256)):
     X, y = synth(K * rows, seed=5)
     b = gp.BCM.split(X, y, K)
     hp = np.array([np.log(3.0), 0.0, np.log(0.1)])
