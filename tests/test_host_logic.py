@@ -40,6 +40,10 @@ def test_no_device_is_an_error_not_a_fallback():
         gp.Covsum(16, 2)
     with pytest.raises(capi.CugpError):
         gp.potrf(np.eye(4))
+    rc = lib.cugp_create_padded(16, 2, 0, 256, C.byref(h))
+    assert rc == -4 and not h.value
+    with pytest.raises(capi.CugpError):                  # the BCM layer creates its experts the same way
+        gp.BCM([8, 8], 2)
 
 
 def test_argument_validation():
