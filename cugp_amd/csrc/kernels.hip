@@ -94,6 +94,7 @@ __device__ __forceinline__ void tile_stage_mma(const char* __restrict__ cur, int
 // LDS image per operand and stage: [k-pair plane (padded by 16 B)][row][2 doubles].
 #ifdef CUGP_TILE_STAMPS   // diagnostic build only (tools/gemm_k_bench.hip): where a tile's time goes
 __device__ unsigned long long g_tile_stamps[64];
+__device__ int g_tile_stamp_on;                          // stamps inside tile_nt only while this is set
 #define TILE_STAMP(i)                                                              \
     do {                                                                           \
         if (threadIdx.x == 0 && blockIdx.x == 200) {                               \
@@ -144,7 +145,9 @@ __device__ __forceinline__ void tile_nt(const double* __restrict__ Ag, int lda, 
         *(d2*)(smem + wb[q]) = rb[q];
     }
     __syncthreads();
-    TILE_STAMP(1);
+#ifdef CUGP_TILE_STAMPS
+    if (g_tile_stamp_on) TILE_STAMP(1);
+#endif
 
     // two stages per trip so both LDS buffers are compile-time offsets (no address arithmetic in the loop)
 #define CUGP_STAGE(HALF, MORE, KNEXT)                                                              \

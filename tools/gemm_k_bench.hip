@@ -21,6 +21,9 @@ __global__ __launch_bounds__(256, 2) void k_gemm_persistent(const double* __rest
         acc_zero(acc);
         if (it == 3) TILE_STAMP(0);
 #ifdef CUGP_TILE_STAMPS
+        if (threadIdx.x == 0 && blockIdx.x == 200) g_tile_stamp_on = (it == 3);
+#endif
+#ifdef CUGP_TILE_STAMPS
         if (threadIdx.x == 0 && (blockIdx.x == 200 || blockIdx.x == 7) && it < 10)
             g_tile_stamps[(blockIdx.x == 7 ? 16 : 48) + it] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -69,7 +72,7 @@ int main()
                2.0 * m * n * k / ms / 1e9, ms * 1e3 / rounds, ms * 1e3 / rounds / (k / 128.0));
         if (k <= 1024) {
             (void)hipFuncSetAttribute((const void*)k_gemm_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-            for (int slots : {512, 768}) {
+            for (int slots : {512, 256}) {
                 hipLaunchKernelGGL(k_gemm_persistent, dim3(slots), dim3(256), GEMM_LDS, 0, A, B, C, n, k, m / 128, (int)tiles);
                 hipDeviceSynchronize();
                 hipEventRecord(e0);
@@ -80,13 +83,16 @@ int main()
                 ms2 /= reps;
                 printf("   persistent x%d: %8.1f us %5.1f TF", slots, ms2 * 1e3, 2.0 * m * n * k / ms2 / 1e9);
 #ifdef CUGP_TILE_STAMPS
-                if (slots == 512) {
+                {
                     unsigned long long st[64];
                     hipMemcpyFromSymbol(st, HIP_SYMBOL(g_tile_stamps), sizeof(st));
                     printf("\n      tile times (us) workgroup 7:");
                     for (int i = 0; i < 8; i++) printf(" %.1f", (st[17 + i] - st[16 + i]) / 100.0);
                     printf("   workgroup 200:");
                     for (int i = 0; i < 8; i++) printf(" %.1f", (st[49 + i] - st[48 + i]) / 100.0);
+                    printf("\n      [%d workgroups] tile 3 (cycles): prologue %lld, k loop %lld, store issue %lld, store drain %lld, barrier %lld",
+                           slots, (long long)(st[1] - st[0]), (long long)(st[2] - st[1]), (long long)(st[3] - st[2]),
+                           (long long)(st[4] - st[3]), (long long)(st[5] - st[4]));
                     printf("\n      two tiles: %lld core cycles in %.2f us (100 MHz counter) = %.0f MHz",
                            (long long)(st[6] - st[0]), (st[38] - st[32]) / 100.0, (st[6] - st[0]) / ((st[38] - st[32]) / 100.0));
                     printf("\n      stamps (cycles from tile start): loop end %lld, stores issued %lld, stores done %lld, barrier %lld, next tile at %lld",
