@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstdint>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -71,9 +72,18 @@ struct cugp_gp {
     int n = 0, d = 0, npad = 0, nt = 0, device = 0;
     hipStream_t stream = nullptr;   // all device work of the handle is ordered here ...
     hipStream_t aux = nullptr;      // ... except the inverse blocks that run beside the factorisation (fork/join by events):
-    hipStream_t aux2 = nullptr;     // aux = the large products, aux2 = each block's own small inverse
+    hipStream_t aux2 = nullptr;     // aux = the large products, aux2 = each block's own small inverse,
+    hipStream_t lq = nullptr;       // lq = each block's share of K^-1 (beside the next block's bordering)
+    hipStream_t wide = nullptr;     // look-ahead Cholesky: the K = P*128 trailing updates beside the panel chain
+    hipStream_t chain = nullptr;    // ... and the panel chain itself, on its OWN compute units (CU-masked streams: a
+    hipStream_t widem = nullptr;    //     latency-bound chain kernel sharing a CU with MFMA tile products runs 3-5x slower)
+    int chain_cus = -1;             // compute units the masked pair was created for
+    hipEvent_t cfork = nullptr, cjoin = nullptr;   // main -> chain at the start of a factorisation, chain -> main at its end
     std::vector<hipEvent_t> bev;    // fork events, one per inverse block, + the join event (last)
     std::vector<hipEvent_t> oev;    // "block's own inverse done" events (aux2 -> aux)
+    std::vector<hipEvent_t> lev;    // "block's inverse rows final" events (aux -> lq) + lq's join event (last)
+    std::vector<hipEvent_t> pnev;   // "panel p factored" (main -> wide)
+    std::vector<hipEvent_t> wev;    // "wide update of panel p reached the next panel's look-ahead columns" (wide -> main) + join (last)
     double *dX = nullptr, *dy = nullptr, *dA = nullptr, *dT = nullptr, *dU = nullptr, *dKinv = nullptr;
     double *dz = nullptr, *dalpha = nullptr, *dw = nullptr, *d16 = nullptr, *dlogdet = nullptr, *dpart = nullptr, *d64 = nullptr;
     double* dout = nullptr;
@@ -102,11 +112,12 @@ struct cugp_gp {
     hipEvent_t pev[NPHASE + 1] = {};
     bool pev_valid = false;
     std::vector<hipEvent_t> kev;   // start/stop pairs around trailing updates
+    std::vector<int> kev_kind;     // per pair: 0 = k_syrk_step, 1 = k_syrk_wide
+    std::vector<double> kev_flopv; // per pair: algorithmic flop of the launch
     int kev_used = 0;
     unsigned eval_seq = 0;         // factorisations enqueued so far (rotates the launches that get timed)
-    double kev_flop = 0, kev_ms_done = 0;
-    long long kev_launches_done = 0;
-    double kev_flop_done = 0;
+    double kst_ms[2] = {0, 0}, kst_flop[2] = {0, 0};   // folded sums per kernel kind
+    long long kst_launches[2] = {0, 0};
 };
 
 namespace {
@@ -151,12 +162,12 @@ void drain_kernel_events(cugp_gp* g)
     for (int i = 0; i + 1 < g->kev_used; i += 2) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, g->kev[i], g->kev[i + 1]) == hipSuccess) {
-            g->kev_ms_done += ms;
-            g->kev_launches_done += 1;
+            const int kd = g->kev_kind[i / 2];
+            g->kst_ms[kd] += ms;
+            g->kst_launches[kd] += 1;
+            g->kst_flop[kd] += g->kev_flopv[i / 2];
         }
     }
-    g->kev_flop_done += g->kev_flop;
-    g->kev_flop = 0;
     g->kev_used = 0;
 }
 
@@ -178,8 +189,11 @@ int pipe_block(const cugp_gp* g, bool with_inverse)
 // Inverse quantities of block rows [a, b): T and U = T^T (diagonal-tile inverses, doubling inside the block,
 // bordering against the finished rows [0, a)) and the block's share of K^-1 = T^T T (when Kinv is wanted).
 // The block's own inverse is a chain of small launches; on its own stream `xs` (when given) it runs beside
-// the large products of the previous block instead of in front of this block's.
-int enqueue_inverse_block(cugp_gp* g, int a, int b, bool kinv, hipStream_t x, hipStream_t xs, hipEvent_t own_done)
+// the large products of the previous block instead of in front of this block's.  The K^-1 share only needs
+// the block's rows of U: on its own stream `lq` (when given) it runs beside the NEXT block's bordering -- two
+// independent large launches in flight fill each other's last, partly empty round of workgroups.
+int enqueue_inverse_block(cugp_gp* g, int a, int b, bool kinv, hipStream_t x, hipStream_t xs, hipEvent_t own_done,
+                          hipStream_t lq = nullptr, hipEvent_t rows_final = nullptr)
 {
     const int ld = g->npad, wb = b - a;
     const size_t off = (size_t)a * TILE * ld + (size_t)a * TILE;
@@ -195,37 +209,168 @@ int enqueue_inverse_block(cugp_gp* g, int a, int b, bool kinv, hipStream_t x, hi
     }
     // rows [a, b): their Wt was accumulated chunk by chunk while the earlier blocks became final
     if (a > 0) launch_trtri_border2(g->dA, g->dT, g->dU, ld, a, wb, x, B(g));
+    if (kinv && lq) {
+        HIPCHK(hipEventRecord(rows_final, x));
+        HIPCHK(hipStreamWaitEvent(lq, rows_final, 0));
+        launch_lauum(g->dU, g->dKinv, ld, a, wb, lq, B(g));
+    }
     // ... and these rows, now final, go into the Wt of every row below them
     if (b < g->nt) launch_trtri_border1(g->dA, g->dT, g->dU, ld, b, g->nt - b, a, b, x, B(g));
-    if (kinv) launch_lauum(g->dU, g->dKinv, ld, a, wb, x, B(g));
+    if (kinv && !lq) launch_lauum(g->dU, g->dKinv, ld, a, wb, x, B(g));
     return CUGP_OK;
 }
 
-// Blocked right-looking Cholesky of A (lower), two launches per step on the main stream:
-//   panel solve(k)  ->  [trailing update(k) + factorisation of diagonal block k+1] in ONE launch
-// (k_syrk_step: the latency-bound diagonal block runs inside the MFMA-bound trailing update).
-// with_inverse: the factorisation's tail is a chain of small launches that leaves most of the chip idle,
-// while L^-1 and K^-1 can be built block row by block row as soon as the rows of L are final -- so every
-// `w` finished block rows are handed to a second, low-priority stream (fork by event) and the main stream
-// joins it at the end.  Each block's work is ordered on that stream, so results do not depend on timing.
 int phase_mark(cugp_gp* g, int i);
 int fetch_eval(cugp_gp* g);
 
-int fork_inverse_block(cugp_gp* g, int a, int b, int idx)
+int fork_inverse_block(cugp_gp* g, int a, int b, int idx, hipStream_t from)
 {
-    HIPCHK(hipEventRecord(g->bev[idx], g->stream));
+    HIPCHK(hipEventRecord(g->bev[idx], from));
     HIPCHK(hipStreamWaitEvent(g->aux, g->bev[idx], 0));
     HIPCHK(hipStreamWaitEvent(g->aux2, g->bev[idx], 0));
-    return enqueue_inverse_block(g, a, b, true, g->aux, g->aux2, g->oev[idx]);
+    const bool own = g_tune[TUNE_LAUUM_STREAM] != 0;
+    return enqueue_inverse_block(g, a, b, true, g->aux, g->aux2, g->oev[idx], own ? g->lq : nullptr,
+                                 own ? g->lev[idx] : nullptr);
 }
 
+// What step kb of the two-speed factorisation launches (pure column arithmetic, shared with the test hook
+// cugp_potrf_plan so the schedule can be replayed on a CPU: every tile must see every k exactly once, in order).
+//
+// Steps are grouped in panels of P.  The step launch (k_syrk_step, K = 128, with the next diagonal block
+// factored inside it) updates only the NEAR window: the tile columns [kb+1, F_p), F_p fixed per panel and chosen
+// so that the window holds about `near` tiles at the panel's first step -- enough to fill the chip for the
+// ~45 us the diagonal block needs, so the latency-bound chain stays hidden exactly as in the classic form.
+// The FAR columns [F_p, nt) get the whole panel at once, K = P*128, from k_syrk_wide when the panel's last
+// column is solved (one pass over their C tiles instead of P: the tile product costs a fixed ~12 us per C tile
+// + 30.5 us per 128 of K).  F_p never decreases, so a column is either inside every later window or was
+// brought up to date by every earlier wide pass.  Once the window reaches the last column (small trailing
+// matrices, where the chain is the bound anyway) this IS the classic right-looking form.
+struct StepPlan {
+    int wide_k0, wide_kw;      // k tiles of the wide update issued at this step (after its panel solve) ...
+    int wa0, wa1, wb0, wb1;    // ... over the tile columns [wa0, wa1) (event after it), then [wb0, wb1); empty: none
+    int wait_panel;            // >= 0: the step launch waits for the first wide launch of that panel (two-stream form)
+    int wcol, la0, kfirst;     // step launch: columns [kb+1, kb+1+wcol); columns >= la0 take k tiles [kfirst, kb]
+};
+
+static int tri_tiles(int n) { return n * (n + 1) / 2; }
+
+// far boundary of panel p: first tile column NOT in the near window
+int far_boundary(int nt, int P, int near, int p)
+{
+    int F = 0;
+    for (int q = 0; q <= p; q++) {                                    // monotone over the panels
+        const int k0 = q * P, m = nt - k0 - 1;                        // trailing size at the panel's first step
+        int wc = P;                                                   // at least the panel itself and one more column
+        while (wc < m && (wc >= m ? tri_tiles(m) : tri_tiles(wc) + (m - wc) * wc) < near) wc++;
+        int f = k0 + 1 + wc;
+        if (f < (q + 1) * P + 1) f = (q + 1) * P + 1;
+        if (f > nt) f = nt;
+        if (f > F) F = f;
+    }
+    return F;
+}
+
+StepPlan plan_step(int nt, int P, int near, int kb)
+{
+    StepPlan sp{0, 0, 0, 0, 0, 0, -1, nt - kb - 1, 1 << 30, kb};
+    if (P <= 1) return sp;                                            // classic: the whole trailing matrix, k = kb
+    const int p = kb / P, i = kb % P;
+    const int F = far_boundary(nt, P, near, p);
+    if (i == P - 1 && F < nt) {
+        sp.wide_k0 = p * P;
+        sp.wide_kw = P;
+        sp.wa0 = F;
+        sp.wa1 = nt;
+    }
+    sp.wcol = F - (kb + 1);
+    return sp;
+}
+
+// The look-ahead factorisation runs its panel chain on `ncu` compute units of its own and the wide updates on
+// the others (hipExtStreamCreateWithCUMask; measured here: a 16-CU stream and its complement do not disturb each
+// other, while a chain kernel sharing CUs with tile products ran 3-5x slower and a prioritised stream still waited
+// for free workgroup slots).  Mask bit i is compute unit i in the runtime's order (dealt round-robin over the
+// 8 XCDs), so the chain gets ncu/8 CUs on every XCD.  (Re)created when the tuning changes.
+int ensure_partition_streams(cugp_gp* g, int ncu)
+{
+    if (g->chain && g->chain_cus == ncu) return CUGP_OK;
+    if (g->chain) { (void)hipStreamSynchronize(g->chain); (void)hipStreamDestroy(g->chain); g->chain = nullptr; }
+    if (g->widem) { (void)hipStreamSynchronize(g->widem); (void)hipStreamDestroy(g->widem); g->widem = nullptr; }
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, g->device));
+    const int total = prop.multiProcessorCount;
+    if (ncu < 8 || ncu > total - 8) return fail(CUGP_ERR_INVALID, "chain compute units out of range");
+    const int words = (total + 31) / 32;
+    std::vector<uint32_t> mc(words, 0u), mw(words, 0u);
+    for (int i = 0; i < total; i++) (i < ncu ? mc : mw)[i / 32] |= 1u << (i % 32);
+    HIPCHK(hipExtStreamCreateWithCUMask(&g->chain, (uint32_t)words, mc.data()));
+    HIPCHK(hipExtStreamCreateWithCUMask(&g->widem, (uint32_t)words, mw.data()));
+    g->chain_cus = ncu;
+    return CUGP_OK;
+}
+
+// panel width of the look-ahead factorisation for this handle (1 = classic right-looking, K = 128 per pass)
+int panel_width(const cugp_gp* g)
+{
+    int P = g_tune[TUNE_PANEL];
+    if (P < 2 || g->nt < g_tune[TUNE_PANEL_MIN_NT] || g->nt < 3 * P) return 1;
+    return P > 16 ? 16 : P;
+}
+
+// one timed launch (profiling level 2): event pair + bookkeeping
+struct TimedLaunch {
+    cugp_gp* g; hipStream_t s; bool on;
+    TimedLaunch(cugp_gp* g_, hipStream_t s_, bool want) : g(g_), s(s_), on(want && g_->kev_used + 2 <= (int)g_->kev.size())
+    {
+        if (on && hipEventRecord(g->kev[g->kev_used], s) != hipSuccess) on = false;
+    }
+    void done(int kind, double flop)
+    {
+        if (!on) return;
+        if (hipEventRecord(g->kev[g->kev_used + 1], s) != hipSuccess) return;
+        g->kev_kind[g->kev_used / 2] = kind;
+        g->kev_flopv[g->kev_used / 2] = flop;
+        g->kev_used += 2;
+    }
+};
+
+// algorithmic flop of a trailing update over the tile columns [ca, cb) of an nt-tile matrix with kw k tiles:
+// entries on or below the diagonal only (a diagonal tile counts half), multiply + add
+double trailing_flop(int nt, int ca, int cb, int kw)
+{
+    if (cb > nt) cb = nt;
+    double entries = 0;
+    for (int c = ca; c < cb; c++) entries += ((double)(nt - c) - 0.5) * TILE * TILE;
+    return entries * kw * TILE * 2.0;
+}
+
+// Blocked right-looking Cholesky of A (lower).  Handle's stream, two launches per step:
+//   panel solve(k)  ->  [trailing update(k) + factorisation of diagonal block k+1] in ONE launch
+// (k_syrk_step: the latency-bound diagonal block runs inside the update launch), and in the two-speed form
+// (panels of P > 1 steps, plan_step above; cpp_matrixalgebra/blocked_cholesky.cpp:221-262 is the b = 2 ancestor)
+// one k_syrk_wide pass per panel over the far columns.  Every tile sees its updates in a fixed order whatever
+// the timing: results are reproducible.
+// with_inverse: L^-1 and K^-1 are built block row by block row on further streams as the rows of L become final.
 int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false)
 {
     int rc;
-    hipStream_t m = g->stream;
     const int nt = g->nt, ld = g->npad;
     const int w = pipe_block(g, with_inverse);
+    const int P = panel_width(g);
+    const int near = g_tune[TUNE_NEAR_TILES];
+    // streams: classic form -- everything on the handle's stream; look-ahead form -- the chain and the wide
+    // updates on disjoint sets of compute units (or, partition off, the chain on the handle's stream)
+    hipStream_t m = g->stream, wq = g_tune[TUNE_WIDE_STREAM] != 0 ? g->wide : g->stream;
+    const int ncu = P > 1 && g_tune[TUNE_WIDE_STREAM] != 0 ? g_tune[TUNE_CHAIN_CUS] : 0;
+    if (ncu > 0) {
+        if ((rc = ensure_partition_streams(g, ncu))) return rc;
+        m = g->chain;
+        wq = g->widem;
+        HIPCHK(hipEventRecord(g->cfork, g->stream));
+        HIPCHK(hipStreamWaitEvent(m, g->cfork, 0));
+    }
     int nblk = 0, done = 0;                                 // blocks forked so far, block rows handed over
+    bool wide_used = false;
     g->eval_seq++;
     if (g->grp) HIPCHK(hipMemsetAsync(g->grp->tickets, 0, (size_t)g->grp->bt.count * nt * sizeof(unsigned), m));
     else HIPCHK(hipMemsetAsync(g->dtickets, 0, (size_t)nt * sizeof(unsigned), m));
@@ -235,26 +380,60 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false)
         // block rows < kb+1 of L are final, and so are the columns <= kb of every row below them
         const int b = kb + 1;
         if (w > 0 && b - done >= w) {
-            if ((rc = fork_inverse_block(g, done, b, nblk))) return rc;
+            if ((rc = fork_inverse_block(g, done, b, nblk, m))) return rc;
             done = b;
             nblk++;
         }
-        // level 2 times a rotating eighth of the launches (every step is sampled once in 8 evaluations):
-        // an event pair around every launch costs several percent of the evaluation
-        const bool ev = g->prof >= 2 && (kb + g->eval_seq) % PROF_STRIDE == 0 && g->kev_used + 2 <= (int)g->kev.size();
-        if (ev) HIPCHK(hipEventRecord(g->kev[g->kev_used], m));
-        launch_syrk_step(g->dA, ld, kb, nt, g->d16, g->d64, g->dlogdet, g->dtickets, m, B(g));
-        if (ev) {
-            HIPCHK(hipEventRecord(g->kev[g->kev_used + 1], m));
-            g->kev_used += 2;
-            const double me = (double)(nt - kb - 1) * TILE;
-            g->kev_flop += me * me * TILE;                  // lower triangle only: m^2 * nb (mul+add)
+        const StepPlan sp = plan_step(nt, P, near, kb);
+        if (sp.wa1 > sp.wa0) {
+            // panel p is factored (its last panel solve is enqueued): everything beyond the look-ahead columns
+            // gets the panel's K = P*128 in one pass -- first the columns the NEXT panel's steps will touch
+            const int p = kb / P;
+            if (wq != m) {
+                HIPCHK(hipEventRecord(g->pnev[p], m));
+                HIPCHK(hipStreamWaitEvent(wq, g->pnev[p], 0));
+            }
+            {
+                TimedLaunch tl(g, wq, g->prof >= 2);
+                launch_syrk_wide(g->dA, ld, nt, sp.wide_k0, sp.wide_kw, sp.wa0, sp.wa1, p & 1, wq, B(g));
+                tl.done(1, trailing_flop(nt, sp.wa0, sp.wa1, sp.wide_kw));
+            }
+            if (wq != m) {                                      // two-stream form: the next step launch must see it done
+                HIPCHK(hipEventRecord(g->wev[p], wq));
+                HIPCHK(hipStreamWaitEvent(m, g->wev[p], 0));
+            }
+            if (sp.wb1 > sp.wb0) {
+                TimedLaunch tl(g, wq, g->prof >= 2);
+                launch_syrk_wide(g->dA, ld, nt, sp.wide_k0, sp.wide_kw, sp.wb0, sp.wb1, p & 1, wq, B(g));
+                tl.done(1, trailing_flop(nt, sp.wb0, sp.wb1, sp.wide_kw));
+            }
+            wide_used = true;
         }
+        if (sp.wait_panel >= 0) HIPCHK(hipStreamWaitEvent(m, g->wev[sp.wait_panel], 0));   // that wide update is done with the look-ahead columns
+        // level 2 times a rotating eighth of the step launches (every step is sampled once in 8 evaluations):
+        // an event pair around every launch costs several percent of the evaluation
+        TimedLaunch tl(g, m, g->prof >= 2 && (kb + g->eval_seq) % PROF_STRIDE == 0);
+        // (look-ahead form: plain stores -- the panel solve that follows reads the column at once, and reading
+        //  freshly non-temporally stored tiles took it 50 us instead of 16)
+        launch_syrk_step(g->dA, ld, kb, nt, g->d16, g->d64, g->dlogdet, g->dtickets, m, B(g), sp.wcol, sp.la0, sp.kfirst,
+                         P > 1 ? g_tune[TUNE_STEP_STREAM] : 1);
+        tl.done(0, trailing_flop(nt, kb + 1, sp.la0 < kb + 1 + sp.wcol ? sp.la0 : kb + 1 + sp.wcol, 1) +
+                       trailing_flop(nt, sp.la0, kb + 1 + sp.wcol, kb + 1 - sp.kfirst));
+    }
+    if (wide_used && wq != m) {                             // (every wide launch was already waited for; this join
+        HIPCHK(hipEventRecord(g->wev.back(), wq));          //  keeps the stream graph closed)
+        HIPCHK(hipStreamWaitEvent(m, g->wev.back(), 0));
+    }
+    if (m != g->stream) {                                   // back to the handle's stream
+        HIPCHK(hipEventRecord(g->cjoin, m));
+        HIPCHK(hipStreamWaitEvent(g->stream, g->cjoin, 0));
+        m = g->stream;
     }
     if (mark && (rc = phase_mark(g, 2))) return rc;         // end of the factorisation on the main stream
     if (w > 0) {
-        if ((rc = fork_inverse_block(g, done, nt, nblk))) return rc;
+        if ((rc = fork_inverse_block(g, done, nt, nblk, m))) return rc;
         HIPCHK(hipEventRecord(g->bev.back(), g->aux));
+        if (g_tune[TUNE_LAUUM_STREAM] != 0) HIPCHK(hipEventRecord(g->lev.back(), g->lq));
         g->joined = false;
     } else if (with_inverse) {
         if ((rc = enqueue_inverse_block(g, 0, nt, true, m, nullptr, nullptr))) return rc;
@@ -269,7 +448,10 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false)
 // main stream waits for the inverse blocks running on the second stream
 int join_inverse(cugp_gp* g)
 {
-    if (!g->joined) HIPCHK(hipStreamWaitEvent(g->stream, g->bev.back(), 0));
+    if (!g->joined) {
+        HIPCHK(hipStreamWaitEvent(g->stream, g->bev.back(), 0));
+        if (g_tune[TUNE_LAUUM_STREAM] != 0) HIPCHK(hipStreamWaitEvent(g->stream, g->lev.back(), 0));
+    }
     g->joined = true;
     return CUGP_OK;
 }
@@ -336,6 +518,8 @@ int enqueue_eval(cugp_gp* g, bool want_grad)
     if ((rc = use_device(g))) return rc;
     if ((rc = ensure_factor_bufs(g))) return rc;
     if (want_grad && (rc = ensure_inverse_bufs(g))) return rc;
+    if (const int pe = prepare_kernels())                     // per-device launch attributes (dynamic LDS sizes)
+        return fail(CUGP_ERR_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)", (hipError_t)pe);
     g->factor_valid = g->inverse_valid = false;
 
     // Replay a captured graph when the evaluation is a single-stream sequence (no hand-over to the other
@@ -432,10 +616,14 @@ int cugp_create_padded(int n, int d, int device, int npad_min, cugp_gp** out)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->aux, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->aux2, hipStreamNonBlocking);
-    g->bev.assign((size_t)g->nt + 1, nullptr);
-    g->oev.assign((size_t)g->nt + 1, nullptr);
-    for (size_t i = 0; i < g->bev.size() && e == hipSuccess; i++) e = hipEventCreateWithFlags(&g->bev[i], hipEventDisableTiming);
-    for (size_t i = 0; i < g->oev.size() && e == hipSuccess; i++) e = hipEventCreateWithFlags(&g->oev[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->lq, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->wide, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->cfork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->cjoin, hipEventDisableTiming);
+    for (std::vector<hipEvent_t>* v : {&g->bev, &g->oev, &g->lev, &g->pnev, &g->wev}) {
+        v->assign((size_t)g->nt + 2, nullptr);
+        for (size_t i = 0; i < v->size() && e == hipSuccess; i++) e = hipEventCreateWithFlags(&(*v)[i], hipEventDisableTiming);
+    }
     if (e == hipSuccess) e = hipMalloc((void**)&g->dX, (size_t)n * d * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&g->dy, (size_t)g->npad * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&g->dz, (size_t)g->npad * sizeof(double));
@@ -467,6 +655,10 @@ int cugp_destroy(cugp_gp* g)
     if (g->stream) (void)hipStreamSynchronize(g->stream);
     if (g->aux) (void)hipStreamSynchronize(g->aux);
     if (g->aux2) (void)hipStreamSynchronize(g->aux2);
+    if (g->lq) (void)hipStreamSynchronize(g->lq);
+    if (g->wide) (void)hipStreamSynchronize(g->wide);
+    if (g->chain) (void)hipStreamSynchronize(g->chain);
+    if (g->widem) (void)hipStreamSynchronize(g->widem);
     double* bufs[] = {g->dX, g->dy, g->dA, g->dT, g->dU, g->dKinv, g->dz, g->dalpha, g->dw, g->d16, g->dlogdet,
                       g->dpart, g->dout, g->d64};
     for (double* p : bufs)
@@ -481,12 +673,17 @@ int cugp_destroy(cugp_gp* g)
     for (int i = 0; i <= NPHASE; i++)
         if (g->pev[i]) (void)hipEventDestroy(g->pev[i]);
     for (hipEvent_t e : g->kev) (void)hipEventDestroy(e);
-    for (hipEvent_t e : g->bev)
-        if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : g->oev)
-        if (e) (void)hipEventDestroy(e);
+    for (std::vector<hipEvent_t>* v : {&g->bev, &g->oev, &g->lev, &g->pnev, &g->wev})
+        for (hipEvent_t e : *v)
+            if (e) (void)hipEventDestroy(e);
     if (g->aux) (void)hipStreamDestroy(g->aux);
     if (g->aux2) (void)hipStreamDestroy(g->aux2);
+    if (g->lq) (void)hipStreamDestroy(g->lq);
+    if (g->wide) (void)hipStreamDestroy(g->wide);
+    if (g->chain) (void)hipStreamDestroy(g->chain);
+    if (g->widem) (void)hipStreamDestroy(g->widem);
+    if (g->cfork) (void)hipEventDestroy(g->cfork);
+    if (g->cjoin) (void)hipEventDestroy(g->cjoin);
     if (g->stream) (void)hipStreamDestroy(g->stream);
     delete g;
     return CUGP_OK;
@@ -874,6 +1071,8 @@ int cugp_set_profiling(cugp_gp* g, int level)
     g->prof = level;
     if (level >= 2 && g->kev.empty()) {
         g->kev.resize(MAX_KEV);
+        g->kev_kind.assign(MAX_KEV / 2, 0);
+        g->kev_flopv.assign(MAX_KEV / 2, 0.0);
         for (auto& e : g->kev) HIPCHK(hipEventCreate(&e));
     }
     return CUGP_OK;
@@ -897,16 +1096,21 @@ int cugp_get_phase_ms(cugp_gp* g, double ms[6])
     return CUGP_OK;
 }
 
-int cugp_get_kernel_stats(cugp_gp* g, double* sum_ms, long long* launches, double* flop, int reset)
+int cugp_get_kernel_stats_kind(cugp_gp* g, int kind, double* sum_ms, long long* launches, double* flop, int reset)
 {
-    if (!g) return CUGP_ERR_INVALID;
+    if (!g || kind < 0 || kind > 1) return CUGP_ERR_INVALID;
     int rc;
     if ((rc = fetch_eval(g))) return rc;
-    if (sum_ms) *sum_ms = g->kev_ms_done;
-    if (launches) *launches = g->kev_launches_done;
-    if (flop) *flop = g->kev_flop_done;
-    if (reset) { g->kev_ms_done = 0; g->kev_launches_done = 0; g->kev_flop_done = 0; }
+    if (sum_ms) *sum_ms = g->kst_ms[kind];
+    if (launches) *launches = g->kst_launches[kind];
+    if (flop) *flop = g->kst_flop[kind];
+    if (reset) { g->kst_ms[kind] = 0; g->kst_launches[kind] = 0; g->kst_flop[kind] = 0; }
     return CUGP_OK;
+}
+
+int cugp_get_kernel_stats(cugp_gp* g, double* sum_ms, long long* launches, double* flop, int reset)
+{
+    return cugp_get_kernel_stats_kind(g, 0, sum_ms, launches, flop, reset);
 }
 
 void* cugp_get_stream(cugp_gp* g) { return g ? (void*)g->stream : nullptr; }
@@ -947,6 +1151,15 @@ int cugp_set_tuning(int key, int value)
     if (key < 0 || key >= TUNE_COUNT) return CUGP_ERR_INVALID;
     if (g_tune[key] != value && key != TUNE_GRAPHS) g_cfg_epoch++;   // launch shapes changed: recapture graphs
     g_tune[key] = value;
+    return CUGP_OK;
+}
+
+int cugp_potrf_plan(int nt, int P, int near, int kb, int out[10])
+{
+    if (!out || nt <= 1 || kb < 0 || kb + 1 >= nt || P < 1) return CUGP_ERR_INVALID;
+    const StepPlan sp = plan_step(nt, P, near, kb);
+    const int v[10] = {sp.wide_k0, sp.wide_kw, sp.wa0, sp.wa1, sp.wb0, sp.wb1, sp.wait_panel, sp.wcol, sp.la0, sp.kfirst};
+    for (int i = 0; i < 10; i++) out[i] = v[i];
     return CUGP_OK;
 }
 

@@ -16,7 +16,15 @@ enum { TUNE_LAUUM_WM2_MAX = 0,   // K^-1 product: use 64x64 tiles when there are
        TUNE_GRAPHS = 5,          // replay single-stream evaluations as a captured HIP graph (1) or launch by launch (0)
        TUNE_GROUP_OVERLAP = 6,   // grouped experts: inverse blocks on the other streams beside the factorisation (1) or after it (0)
        TUNE_GROUP_MAX_TILES = 7, // experts up to this many tiles share launches (default: all; with the inverse beside the factorisation grouping won at every size tried: 4 x 6000 rows 18.9 -> 18.3 ms, 2 x 8192 rows 23.6 -> 21.9 ms)
-       TUNE_COUNT = 8 };
+       TUNE_PANEL = 8,           // two-speed Cholesky: steps per panel (far columns get K = 128*this in one pass per panel); 1 = classic
+       TUNE_NEAR_TILES = 9,      // ... tiles in the near window (updated every step, K = 128) at a panel's first step
+       TUNE_WIDE_GRID = 10,      // ... workgroups of the wide update (a bound only matters beside other streams)
+       TUNE_PANEL_MIN_NT = 11,   // ... only from this many tiles on (small matrices are bound by the chain alone)
+       TUNE_LAUUM_STREAM = 12,   // the K^-1 share of an inverse block on its own stream beside the next block's bordering (1) or behind it (0)
+       TUNE_STEP_STREAM = 13,    // two-speed step kernel: non-temporal accesses to the C tiles (1) or plain ones (0)
+       TUNE_CHAIN_CUS = 14,      // experimental two-stream form: compute units reserved for the panel chain (CU-masked streams); 0 = no partition
+       TUNE_WIDE_STREAM = 15,    // wide updates on the handle's stream (0) or on their own stream beside the next panel's chain (1, experimental)
+       TUNE_COUNT = 16 };
 extern int g_tune[TUNE_COUNT];
 
 struct HyperScalars;
@@ -59,8 +67,12 @@ void launch_trsm_inv64(double* A, const double* d64, int ld, int kb, int nt, hip
 void launch_trtri_diag(const double* A, int ld, int kb, int nblocks, const double* d64, double* T, double* U,
                        hipStream_t s, Batch bt = {});
 // trailing update of step kb fused with the factorisation of diagonal block kb+1 (tickets[kb] must be 0)
+// wcol > 0: only the tile columns [kb+1, kb+1+wcol); columns >= la0 take the k tiles [kfirst, kb] (look-ahead form)
 void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* d64, double* logdet_part,
-                      unsigned* tickets, hipStream_t s, Batch bt = {});
+                      unsigned* tickets, hipStream_t s, Batch bt = {}, int wcol = 0, int la0 = 1 << 30, int kfirst = 0,
+                      int stream_c = 1);
+// wide trailing update: tile columns [ca, cb) (rows >= column) -= L(., k tiles [k0, k0+kw)) L(.)^T; returns tiles
+int launch_syrk_wide(double* A, int ld, int nt, int k0, int kw, int ca, int cb, int rev, hipStream_t s, Batch bt = {});
 
 // ---- triangular inverse by recursive doubling (N7) and K^-1 = U U^T (N8) ----
 // off: element offset of the diagonal sub-matrix (nt tiles) the level works on inside L, T, U
@@ -98,8 +110,9 @@ void launch_trace(const double* X, int n, int d, int npad, HyperScalars h, const
 void launch_finalize(const double* z, int npad, int n, const double* logdet_part, int nt, const double* part,
                      int nblocks, HyperScalars h, double* out, hipStream_t s, const HyperScalars* hd = nullptr,
                      Batch bt = {});
-// one-time function attributes (dynamic LDS sizes); the launchers do it lazily, a stream capture must not
-void prepare_kernels();
+// per-device function attributes (dynamic LDS sizes) for the current device; the launchers do it lazily, a
+// stream capture must not.  Returns the hipError_t of a failed hipFuncSetAttribute (0 = fine).
+int prepare_kernels();
 
 // test hook: C[m x n] = A[m x k] * B[n x k]^T on the MFMA tile path (all multiples of 128 / 16)
 void launch_test_gemm_nt(const double* A, const double* B, double* C, int m, int n, int k, hipStream_t s);

@@ -64,6 +64,16 @@ __device__ __forceinline__ int bpos(int R)
     return (R - q) + (((q >> 5) * 2 + (q & 1)) * 16) + ((q & 31) >> 1);
 }
 
+// threadIdx.x behind an optimisation barrier: inside a persistent tile loop (k_syrk_wide) the compiler would
+// otherwise hoist every per-thread address of the tile product out of the loop and keep them all live across
+// the accumulator load / store, which overflows the 256-register budget of 2 workgroups per CU into scratch.
+__device__ __forceinline__ int opaque_tid()
+{
+    int t = threadIdx.x;
+    asm volatile("" : "+v"(t));
+    return t;
+}
+
 // One K stage (16 deep) of MFMAs out of LDS buffer `cur`.  Measured on gfx950: every VALU instruction a wave
 // issues between fp64 MFMAs costs MFMA issue time (pure MFMA stream 74 TF/s, +1 VALU per MFMA 62, +4: 55),
 // so the loop body carries NO address arithmetic: fragment addresses are one per-lane base + immediates.
@@ -111,7 +121,7 @@ __device__ __forceinline__ void tile_nt(const double* __restrict__ Ag, int lda, 
                                         int ldb, int kbeg, int kend, d4 (&acc)[WM][WM], char* smem)
 {
     typedef Geo<WM> G;
-    const int t = threadIdx.x;
+    const int t = opaque_tid();
     const int lane = t & 63, wave = t >> 6;
     const int wr = wave >> 1, wc = wave & 1;
 
@@ -201,7 +211,8 @@ __device__ __forceinline__ void acc_zero(d4 (&acc)[WM][WM])
 template <bool STREAM = false, int WM>
 __device__ __forceinline__ void tile_load(const double* __restrict__ C, int ldc, d4 (&acc)[WM][WM])
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid = opaque_tid();
+    const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
 #pragma unroll
     for (int m = 0; m < WM; m++)
@@ -220,7 +231,8 @@ __device__ __forceinline__ void tile_load(const double* __restrict__ C, int ldc,
 template <bool STREAM = false, int WM>
 __device__ __forceinline__ void tile_store(double* __restrict__ C, int ldc, const d4 (&acc)[WM][WM], double alpha)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid = opaque_tid();
+    const int lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
 #pragma unroll
     for (int m = 0; m < WM; m++)
@@ -284,6 +296,18 @@ __device__ __forceinline__ void tri_index(int idx, int& ti, int& tj)
     while (r * (r + 1) / 2 > idx) r--;
     ti = r;
     tj = idx - r * (r + 1) / 2;
+}
+
+// Tiles (ti >= tj) of the tile columns [0, wcol) of a lower triangle, row by row: row r holds min(r + 1, wcol)
+// tiles.  idx -> (ti, tj), both relative to the region's first column.  wcol >= the triangle's size gives the
+// whole triangle (tri_index).
+__device__ __forceinline__ void trap_index(int idx, int wcol, int& ti, int& tj)
+{
+    const int head = wcol * (wcol + 1) / 2;
+    if (idx < head) { tri_index(idx, ti, tj); return; }
+    const int rem = idx - head;
+    ti = wcol + rem / wcol;
+    tj = rem % wcol;
 }
 
 // ---- K^-1 (lower tiles, diagonal tiles complete) = U * U^T, U = L^-T upper, taken one block of
@@ -988,8 +1012,8 @@ __device__ __forceinline__ void diag_update_wave(double* __restrict__ A, int ld,
 // ------------------------------------------------------------------------------------------
 // One launch per factorisation step kb: the trailing update A22 -= L21 L21^T AND, inside it, the
 // factorisation of the NEXT diagonal block.  Workgroups 0..8 (dispatched first) update the 36 micro
-// tiles of tile (kb+1,kb+1) straight from L2; the last of them to finish (agent-scope release ->
-// ticket -> acquire, no spinning) goes on to factor that block (potf2_body) while the other
+// tiles of tile (kb+1,kb+1) straight from L2; the last of them to finish (acq_rel ticket at agent
+// scope, no spinning) goes on to factor that block (potf2_body) while the other
 // workgroups of the launch run the MFMA tile products of the rest of the trailing matrix.  The
 // latency-bound diagonal block therefore never waits for a free CU slot and needs no second stream.
 // ------------------------------------------------------------------------------------------
@@ -997,11 +1021,16 @@ constexpr int NDIAGWG = NLT / 4;                      // 9 workgroups x 4 waves 
 constexpr int STEP_LDS = POTF2_LDS;                   // >= GEMM_LDS (66048); two such workgroups still fit one CU
 static_assert(POTF2_LDS >= GEMM_LDS, "the fused step kernel sizes its LDS for both roles");
 
+// wcol / la0 / kfirst (look-ahead form, enqueue_potrf): the launch updates only the tile columns
+// [kb+1, kb+1+wcol) -- the rest of the current panel and the next panel -- and the far columns are brought up to
+// date once per panel by k_syrk_wide with K = P*128.  Columns >= la0 (absolute) take the k tiles [kfirst, kb]
+// instead of kb alone: the first steps of a panel leave the next panel's columns to the wide update still
+// running on them and catch up in one pass.  wcol >= the trailing size, la0 >= nt: the classic full update.
 __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, int ld, int kb,
                                                       double* __restrict__ d16, double* __restrict__ d64,
                                                       double* __restrict__ logdet_part,
-                                                      unsigned* __restrict__ tickets, int nfull,
-                                                      const ExpertPtrs* __restrict__ bt)
+                                                      unsigned* __restrict__ tickets, int nfull, int wcol, int la0,
+                                                      int kfirst, int stream_c, const ExpertPtrs* __restrict__ bt)
 {
     // batched: the EXPERT is the fast grid index, so the diagonal-block workgroups of all experts are
     // dispatched before any tile product (the serial chain of every expert starts at launch)
@@ -1018,18 +1047,17 @@ __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, in
         // (this launch's own tiles and the inverse blocks running on the other streams)
         __builtin_amdgcn_s_setprio(3);
         diag_update_wave(A, ld, kb, bid * 4 + (threadIdx.x >> 6));
-        // publish (cdna guide G16, counter form with write-through stores): every wave drains its sc1 stores,
-        // workgroup barrier, then ONE lane draws the ticket (no agent release needed for sc1 stores)
+        // publish: every wave drains its (agent-scope, write-through) tile stores, workgroup barrier, then ONE
+        // lane draws the ticket with acquire-release semantics at agent scope -- the release orders this
+        // workgroup's tile before the ticket, the acquire of the last arriver orders the ticket before its reads
+        // of the other eight workgroups' tiles (HIP memory model; no reliance on how the stores are encoded)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0)
-            s_ticket = __hip_atomic_fetch_add(&tickets[kb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_ticket = __hip_atomic_fetch_add(&tickets[kb], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if (s_ticket != NDIAGWG - 1) return;           // not the last arriver
-        if (threadIdx.x == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // every wave of the last arriver (its L1/K-cache lines)
         __syncthreads();
         const int kn = kb + 1;
         potf2_body(A + (size_t)kn * TILE * ld + kn * TILE, ld, d16 + (size_t)kn * NMT * (MT * MT),
@@ -1041,7 +1069,6 @@ __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, in
     // Regular tiles: `nfull` of them as 128x128 workgroups; the rest (a partial last round that would
     // leave most of the chip idle for a whole tile time) as four 64x64 workgroups each.
     __builtin_amdgcn_s_setprio(1);                      // ahead of the inverse-block products (priority 0)
-    const int k0 = kb * TILE;
     const int x = bid - NDIAGWG;
     if (x < nfull) {
         // Workgroups are dealt round-robin over the 8 XCDs (private L2 each): give every XCD one contiguous
@@ -1050,20 +1077,58 @@ __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, in
         int ti, tj;
         const int xg = x & 7, xq = nfull >> 3, xr = nfull & 7;
         const int tlin = (xg < xr ? xg * (xq + 1) : xr * (xq + 1) + (xg - xr) * xq) + (x >> 3) + 1;
-        tri_index((kb & 1) ? nfull + 1 - tlin : tlin, ti, tj);       // tile 0 = (kb+1,kb+1) is the diagonal one
+        trap_index((kb & 1) ? nfull + 1 - tlin : tlin, wcol, ti, tj);   // tile 0 = (kb+1,kb+1) is the diagonal one
         const int i0 = (kb + 1 + ti) * TILE, j0 = (kb + 1 + tj) * TILE;
+        const int kf = (kb + 1 + tj >= la0) ? kfirst : kb;
         d4 acc[4][4];
-        tile_load<true>(A + (size_t)i0 * ld + j0, ld, acc);
-        tile_nt<true>(A + (size_t)i0 * ld + k0, ld, A + (size_t)j0 * ld + k0, ld, 0, TILE, acc, (char*)sm);
-        tile_store<true>(A + (size_t)i0 * ld + j0, ld, acc, 1.0);
+        if (stream_c) tile_load<true>(A + (size_t)i0 * ld + j0, ld, acc);
+        else tile_load<false>(A + (size_t)i0 * ld + j0, ld, acc);
+        tile_nt<true>(A + (size_t)i0 * ld, ld, A + (size_t)j0 * ld, ld, kf * TILE, (kb + 1) * TILE, acc, (char*)sm);
+        if (stream_c) tile_store<true>(A + (size_t)i0 * ld + j0, ld, acc, 1.0);
+        else tile_store<false>(A + (size_t)i0 * ld + j0, ld, acc, 1.0);
     } else {
         int ti, tj;
         const int y = x - nfull;
-        tri_index(nfull + 1 + (y >> 2), ti, tj);
+        trap_index(nfull + 1 + (y >> 2), wcol, ti, tj);
+        const int kf = (kb + 1 + tj >= la0) ? kfirst : kb;
         const int i0 = (kb + 1 + ti) * TILE + ((y >> 1) & 1) * 64, j0 = (kb + 1 + tj) * TILE + (y & 1) * 64;
         d4 acc[2][2];
         tile_load<true>(A + (size_t)i0 * ld + j0, ld, acc);
-        tile_nt<true>(A + (size_t)i0 * ld + k0, ld, A + (size_t)j0 * ld + k0, ld, 0, TILE, acc, (char*)sm);
+        tile_nt<true>(A + (size_t)i0 * ld, ld, A + (size_t)j0 * ld, ld, kf * TILE, (kb + 1) * TILE, acc, (char*)sm);
+        tile_store<true>(A + (size_t)i0 * ld + j0, ld, acc, 1.0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Wide trailing update (look-ahead Cholesky): A(ti,tj) -= sum_{k in [k0, k0+kw)} L(ti,k) L(tj,k)^T for the tile
+// columns tj in [ca, cb), ti >= tj -- ONE pass over the C tiles with K = kw*128 (the tile product costs a fixed
+// ~12 us per C tile + 30.5 us per 128 of K: 50 TF/s at K=128, 67 at K=512).  Runs on its own stream beside
+// the panel chain (potf2 / panel solve / narrow k_syrk_step), so the grid is BOUNDED (gridDim.x workgroups walk
+// the tile list with a stride): the chain's launches always find free workgroup slots instead of queueing
+// behind a full wave of 134-us tiles.  gridDim.x is a multiple of 8, so a workgroup stays on one XCD and
+// every XCD walks one contiguous run of the (row-major) tile list: neighbours share panel rows in its L2.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_syrk_wide(double* __restrict__ A, int ld, int k0, int kw, int ca,
+                                                      int cb, int ntiles, int rev,
+                                                      const ExpertPtrs* __restrict__ bt)
+{
+    if (bt) A = bt[blockIdx.y].A;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __builtin_amdgcn_s_setprio(1);
+    const int G = gridDim.x, xg = blockIdx.x & 7;
+    const int xq = ntiles >> 3, xr = ntiles & 7;
+    const int run0 = xg < xr ? xg * (xq + 1) : xr * (xq + 1) + (xg - xr) * xq;   // first tile of my XCD's run
+    const int runlen = xq + (xg < xr ? 1 : 0);
+    for (int r = blockIdx.x >> 3; r < runlen; r += G >> 3) {
+        int ti, tj;
+        const int tlin = run0 + r;
+        trap_index(rev ? ntiles - 1 - tlin : tlin, cb - ca, ti, tj);
+        // (wave-uniform, but the sqrt of the index map runs on the vector unit: move the result back to SGPRs so
+        // the tile coordinates do not hold vector registers across the K loop)
+        const int i0 = __builtin_amdgcn_readfirstlane((ca + ti) * TILE), j0 = __builtin_amdgcn_readfirstlane((ca + tj) * TILE);
+        d4 acc[4][4];
+        tile_load<true>(A + (size_t)i0 * ld + j0, ld, acc);
+        tile_nt<true>(A + (size_t)i0 * ld, ld, A + (size_t)j0 * ld, ld, k0 * TILE, (k0 + kw) * TILE, acc, smem);
         tile_store<true>(A + (size_t)i0 * ld + j0, ld, acc, 1.0);
     }
 }
@@ -1343,7 +1408,7 @@ __global__ __launch_bounds__(256) void k_predict_finish(const double* __restrict
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-int g_tune[TUNE_COUNT] = {768, 1200, 384, -1, 511, 1, 1, 1 << 20};   // defaults chosen by interleaved A/B runs (tools/ab.py)
+int g_tune[TUNE_COUNT] = {768, 1200, 384, -1, 511, 1, 1, 1 << 20, 4, 700, 1 << 20, 32, 1, 1, 0, 0};   // defaults chosen by interleaved A/B runs (tools/ab.py)
 
 static inline int tri_count(int n) { return n * (n + 1) / 2; }
 
@@ -1368,20 +1433,32 @@ void launch_kcross(const double* X, int n, int d, int npad, const double* Xt, in
                        Ks);
 }
 
-static bool g_attr_done = false;
+// hipFuncAttributeMaxDynamicSharedMemorySize applies to the CURRENT device only: one flag per device, and a
+// failure is kept (the launch that follows would be rejected) and reported by prepare_kernels().
+static unsigned long long g_attr_done = 0;              // bit per device ordinal (< 64)
+static hipError_t g_attr_err = hipSuccess;
 static void set_big_lds()
 {
-    if (g_attr_done) return;
-    (void)hipFuncSetAttribute((const void*)k_potf2, hipFuncAttributeMaxDynamicSharedMemorySize, POTF2_LDS);
-    (void)hipFuncSetAttribute((const void*)k_syrk_step, hipFuncAttributeMaxDynamicSharedMemorySize, STEP_LDS);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) dev = 63;
+    if (g_attr_done >> dev & 1ull) return;
+    hipError_t e = hipSuccess;
+    auto attr = [&](const void* f, int bytes) {
+        const hipError_t r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (r != hipSuccess && e == hipSuccess) e = r;
+    };
+    attr((const void*)k_potf2, POTF2_LDS);
+    attr((const void*)k_syrk_step, STEP_LDS);
+    attr((const void*)k_syrk_wide, GEMM_LDS);
     const void* gemm4[] = {(const void*)k_trtri_level<4>, (const void*)k_trtri_border<4>, (const void*)k_lauum<4>,
                            (const void*)k_predict_gemm, (const void*)k_test_gemm};
-    for (const void* f : gemm4) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
-    (void)hipFuncSetAttribute((const void*)k_trtri_diag, hipFuncAttributeMaxDynamicSharedMemorySize, TRTRI_LDS);
-    g_attr_done = true;
+    for (const void* f : gemm4) attr(f, GEMM_LDS);
+    attr((const void*)k_trtri_diag, TRTRI_LDS);
+    if (e != hipSuccess) { g_attr_err = e; return; }
+    g_attr_done |= 1ull << dev;
 }
 
-void prepare_kernels() { set_big_lds(); }
+int prepare_kernels() { set_big_lds(); return (int)g_attr_err; }
 
 void launch_potf2(double* A, int ld, int kb, double* d16, double* d64, double* logdet_part, hipStream_t s, Batch bt)
 {
@@ -1403,20 +1480,41 @@ void launch_trtri_diag(const double* A, int ld, int kb, int nblocks, const doubl
     hipLaunchKernelGGL(k_trtri_diag, dim3(nblocks, bt.count), dim3(256), TRTRI_LDS, s, A, ld, kb, d64, T, U, bt.tab);
 }
 
+static inline int trap_count(int m, int wcol)          // tiles (ti >= tj) of the first wcol columns of an m-triangle
+{
+    return wcol >= m ? tri_count(m) : tri_count(wcol) + (m - wcol) * wcol;
+}
+
 void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* d64, double* logdet_part,
-                      unsigned* tickets, hipStream_t s, Batch bt)
+                      unsigned* tickets, hipStream_t s, Batch bt, int wcol, int la0, int kfirst, int stream_c)
 {
     const int m = nt - kb - 1;
     if (m <= 0) return;
     set_big_lds();
+    if (wcol <= 0 || wcol > m) wcol = m;
     // tiles beyond the last full round of 512 workgroup slots run as 64x64 quarters when that round
     // would be less than three quarters full
-    const int ntl = tri_count(m) - 1;
+    const int ntl = trap_count(m, wcol) - 1;
     int nfull = ntl;
     if (ntl >= 512 && (ntl % 512) <= g_tune[TUNE_SYRK_REM_MAX]) nfull = ntl - ntl % 512;
     const unsigned nwg = NDIAGWG + nfull + 4 * (ntl - nfull);
     hipLaunchKernelGGL(k_syrk_step, bt.tab ? dim3(bt.count, nwg) : dim3(nwg), dim3(256), STEP_LDS, s, A, ld, kb, d16,
-                       d64, logdet_part, tickets, nfull, bt.tab);
+                       d64, logdet_part, tickets, nfull, wcol, la0, kfirst, stream_c, bt.tab);
+}
+
+// tile columns [ca, cb) (rows >= column) -= L(., k0..k0+kw) L(., k0..k0+kw)^T; returns the number of tiles
+int launch_syrk_wide(double* A, int ld, int nt, int k0, int kw, int ca, int cb, int rev, hipStream_t s, Batch bt)
+{
+    if (cb > nt) cb = nt;
+    if (ca >= cb || kw <= 0) return 0;
+    set_big_lds();
+    const int ntiles = trap_count(nt - ca, cb - ca);
+    int G = g_tune[TUNE_WIDE_GRID] & ~7;               // bounded grid: the panel chain keeps finding free slots
+    if (G < 8) G = 8;
+    if (G > ((ntiles + 7) & ~7)) G = (ntiles + 7) & ~7;
+    hipLaunchKernelGGL(k_syrk_wide, dim3(G, bt.count), dim3(256), GEMM_LDS, s, A, ld, k0, kw, ca, cb, ntiles, rev,
+                       bt.tab);
+    return ntiles;
 }
 
 void launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, int s, int step, hipStream_t st,

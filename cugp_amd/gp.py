@@ -14,7 +14,9 @@ from .capi import check, f64, ptr
 
 class Covsum:
     """One GP expert on one GPU.  Covsum(n, d) as covkernel.cpp:14-37; X, y are given per call as in
-    the reference and uploaded when they change (identity of the arrays is the cache key)."""
+    the reference and uploaded whenever their CONTENTS differ from what the GPU holds (the reference
+    recomputes K from the arguments on every call; comparing n*d doubles is nothing beside an O(n^3)
+    evaluation, and an in-place edit of y or a recycled array address can not go unnoticed)."""
 
     def __init__(self, n, d, device=0, npad_min=0):
         self.n, self.d, self.device = int(n), int(d), int(device)
@@ -44,7 +46,7 @@ class Covsum:
         if X.shape != (self.n, self.d) or y.shape != (self.n,):
             raise ValueError("expected X %s and y %s" % ((self.n, self.d), (self.n,)))
         check(capi.lib().cugp_set_data(self._h, ptr(X), ptr(y)))
-        self._data_key = None
+        self._data_key = (X.copy(), y.copy())
 
     def set_data_device(self, dX_ptr, dy_ptr):
         check(capi.lib().cugp_set_data_device(self._h, C.c_void_p(dX_ptr), C.c_void_p(dy_ptr)))
@@ -53,10 +55,11 @@ class Covsum:
     def _bind(self, X, y):
         if X is None:
             return
-        key = (id(X), id(y))
-        if key != self._data_key:
+        X = f64(X)
+        y = f64(y) if y is not None else (self._data_key[1] if self._data_key is not None else np.zeros(self.n))
+        k = self._data_key
+        if k is None or k[0].shape != X.shape or not np.array_equal(k[0], X) or not np.array_equal(k[1], y):
             self.set_data(X, y)
-            self._data_key = key
 
     # -- hyper-parameters --
     def set_loghyperparam(self, hp):
@@ -109,9 +112,7 @@ class Covsum:
     # -- intermediates --
     def compute_K_train(self, X=None):
         """Covsum::compute_K_train(X, out): the full symmetric n x n covariance (labels are not used)."""
-        if X is not None and (self._data_key is None or self._data_key[0] != id(X)):
-            self.set_data(X, np.zeros(self.n))
-            self._data_key = (id(X), None)
+        self._bind(X, None)
         K = np.empty((self.n, self.n))
         check(capi.lib().cugp_compute_K_train(self._h, ptr(K)))
         return K

@@ -117,6 +117,9 @@ int cugp_potrs_vec(int n, const double *K, const double *y, double *x, int devic
 int cugp_set_profiling(cugp_gp *gp, int level /* 0 off, 1 phases, 2 phases + per-launch SYRK events */);
 int cugp_get_phase_ms(cugp_gp *gp, double ms[6]);
 int cugp_get_kernel_stats(cugp_gp *gp, double *sum_ms, long long *launches, double *flop, int reset);
+/* the same per kernel: kind 0 = k_syrk_step (narrow update + diagonal block, K = 128; timed one launch in 8),
+ * kind 1 = k_syrk_wide (look-ahead Cholesky: the far trailing matrix once per panel, K = 128 * panel width) */
+int cugp_get_kernel_stats_kind(cugp_gp *gp, int kind, double *sum_ms, long long *launches, double *flop, int reset);
 void *cugp_get_stream(cugp_gp *gp);          /* hipStream_t of the handle */
 
 /* ---- optimisers (host logic): Covsum::cg_solve covkernel.cpp:405-647 == cg_solve(BCM)
@@ -167,6 +170,11 @@ int cugp_mfma_peak_tflops(int device, double *tflops);
  * 4 plain C = K K^T with uniform tiles (cublas_matrix_multiply.cpp) */
 int cugp_bench_la(int op, int n, int device, int reps, double *ms);
 int cugp_set_tuning(int key, int value);     /* launch-shape thresholds (kernels.h TUNE_*), for A/B runs */
+/* the launches of step kb of the two-speed Cholesky with panels of P steps and a near window of about `near_tiles`
+ * tiles (pure arithmetic, no device): out = {wide k0, wide k tiles, wide columns [a0,a1) then [b0,b1), panel whose
+ * wide update the step waits for or -1, step-launch width in tile columns from kb+1, first column taking several
+ * k tiles, first k tile those take}; tests/test_host_logic.py replays it: every tile sees every k exactly once */
+int cugp_potrf_plan(int nt, int P, int near_tiles, int kb, int out[10]);
 
 #ifdef __cplusplus
 }

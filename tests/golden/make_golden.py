@@ -12,6 +12,11 @@ Outputs : expected values computed by the reference's own C++ compiled where it
 Also    : the numeric trace of the reference's committed run log
           cuda_bettersinglenode_ver2/REF -> ref_log_si128.json
 
+Round 2 (configs 3-5 and a dense metric-size case; CPU-hours, so one job per
+process, see run_jobs.sh):
+    python tests/golden/make_golden.py --job data        # data_si24000.npz, data_siproper_10000.npz
+    python tests/golden/make_golden.py --job NAME        # -> golden_r2/NAME.json  (NAME: see JOBS)
+
 Only data (inputs, expected outputs) is written; no reference source text.
 """
 import argparse
@@ -185,14 +190,106 @@ def big(r, n):
     dump(name, cur)
 
 
+# ---------------------------------------------------------------------------
+# round 2: configs 3-5 on the reference's own data, dense K at the metric size
+# ---------------------------------------------------------------------------
+SC = os.path.join(REF, "scaling_dataset")
+HP_TWO = [2.0, 2.0, 2.0]                          # cuda_scalingdist/main.cpp:298-301
+R2 = os.path.join(HERE, "golden_r2")
+
+
+def make_data():
+    """data_si24000.npz (configs 4+5 share rows) and data_siproper_10000.npz (config 3)."""
+    X = np.loadtxt(os.path.join(SC, "si24000_all_input.txt"), delimiter=",")
+    y = np.loadtxt(os.path.join(SC, "si24000_all_label.txt"))
+    # the chunk files hold the same rows: 4 x 6000 (chunked_dataset) and 16 x 1500 (scaling_dataset)
+    for k in range(4):
+        Xk = np.loadtxt(os.path.join(DS, "si6000_chunk%d.txt" % k), skiprows=1)
+        yk = np.loadtxt(os.path.join(DS, "si6000_label%d.txt" % k))
+        assert np.array_equal(Xk, X[6000 * k:6000 * (k + 1)]) and np.array_equal(yk, y[6000 * k:6000 * (k + 1)]), k
+    for k in range(16):
+        Xk = np.loadtxt(os.path.join(SC, "si24000_16sharded_chunk%d.txt" % k), skiprows=1)
+        yk = np.loadtxt(os.path.join(SC, "si24000_16sharded_label%d.txt" % k))
+        assert np.array_equal(Xk, X[1500 * k:1500 * (k + 1)]) and np.array_equal(yk, y[1500 * k:1500 * (k + 1)]), k
+    np.savez_compressed(os.path.join(HERE, "data_si24000.npz"), X=X, y=y)
+    X, y = load_txt("siproper_10000_10")
+    assert X.shape == (10000, 10)
+    np.savez_compressed(os.path.join(HERE, "data_siproper_10000.npz"), X=X, y=y)
+    print("wrote data_si24000.npz, data_siproper_10000.npz")
+
+
+def _rows(which):
+    if which == "d8192":
+        d = np.load(os.path.join(HERE, "data_siproper_9192.npz"))
+        return d["X"][:8192], d["y"][:8192]
+    if which == "s10000":
+        d = np.load(os.path.join(HERE, "data_siproper_10000.npz"))
+        return d["X"], d["y"]
+    d = np.load(os.path.join(HERE, "data_si24000.npz"))
+    m = re.match(r"si6000_(\d)$", which)
+    if m:
+        k = int(m.group(1))
+        return d["X"][6000 * k:6000 * (k + 1)], d["y"][6000 * k:6000 * (k + 1)]
+    return d["X"], d["y"]
+
+
+def job(r, name):
+    """One reference computation -> golden_r2/<name>.json."""
+    os.makedirs(R2, exist_ok=True)
+    t0 = time.time()
+    if name == "si24000_bcm16":
+        # config 5: 16 x 1500 rows, in-memory BCM (BCM.cpp:85-110 partitions rows exactly like the chunk files)
+        X, y = _rows("si24000")
+        out = {"K": 16, "rows": [0, 24000], "cases": []}
+        Xt = np.vstack([X[:4] * 0.9 + 0.05, X[12000:12004] * 0.8 - 0.1])
+        yt = np.concatenate([y[:4], y[12000:12004]])
+        for hp in (HP_DENSE, HP_TWO):
+            b = r.bcm(X, y, 16, hp)
+            log = os.path.join(tempfile.mkdtemp(), "ll.log")
+            ll = b.loglik(log)
+            per = [float(m.group(1)) for m in re.finditer(r"LL of Expert \d+: ([-\d.]+)", open(log).read())]
+            g = b.grad()
+            m, v = b.predict(Xt)
+            out["cases"].append({"hp": hp, "ll": ll, "ll_per_expert_6dp": per, "grad": g.tolist(), "Xt": Xt.tolist(),
+                                 "yt": yt.tolist(), "pred_mean": m.tolist(), "pred_var": v.tolist(),
+                                 "nlpp": b.nlpp(yt, m, v)})
+    else:
+        m = re.match(r"(d8192|s10000|si6000_\d)_(ll|grad)(_two)?$", name)
+        if not m:
+            raise SystemExit("unknown job " + name)
+        X, y = _rows(m.group(1))
+        hp = HP_TWO if m.group(3) else HP_DENSE
+        out = {"rows": m.group(1), "n": int(X.shape[0]), "hp": hp}
+        if m.group(2) == "ll":
+            out["ll"] = r.loglik(X, y, hp)
+        else:
+            out["grad"] = r.grad(X, y, hp).tolist()
+    out["t_s"] = round(time.time() - t0, 1)
+    with open(os.path.join(R2, name + ".json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote golden_r2/%s.json in %.0f s" % (name, out["t_s"]))
+
+
+JOBS = (["s10000_grad", "d8192_grad", "s10000_ll"] + ["si6000_%d_grad" % k for k in range(4)] + ["d8192_ll"]
+        + ["si6000_%d_ll" % k for k in range(4)] + ["si24000_bcm16"])      # longest first
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--big", type=int, default=0)
+    ap.add_argument("--job", default="")
     a = ap.parse_args()
     from oracle.oracle_py import Reference, build
+    if a.job == "list":
+        print("\n".join(JOBS))
+        raise SystemExit(0)
+    if a.job == "data":
+        make_data()
+        raise SystemExit(0)
     build(ref=True)
     ref = Reference()
-    if a.big:
+    if a.job:
+        job(ref, a.job)
+    elif a.big:
         big(ref, a.big)
     else:
         small(ref)

@@ -133,3 +133,50 @@ def test_row_partition_matches_reference(oracle, si128):
         b = oracle.bcm(X, y, K, HP_BCM)
         assert split_rows(128, K) == [b.expert_rows(k) for k in range(K)]
     assert [expert_owner(k, 3) for k in range(7)] == [0, 1, 2, 0, 1, 2, 0]     # chunk i -> worker i mod W
+
+
+# ---------------------------------------------------------------------------------------------
+# two-speed Cholesky: the launch schedule (cugp_potrf_plan = the arithmetic enqueue_potrf uses)
+# ---------------------------------------------------------------------------------------------
+def _replay_potrf_plan(nt, P, near):
+    """Replay the schedule on a set model.  applied[(i, j)] = k tiles subtracted from tile (i, j) so far, in
+    launch order (one in-order stream).  Checks that every tile has seen exactly k = 0..j-1, ascending, when its
+    column is solved / its diagonal block factored, and that the far boundary never moves backwards."""
+    lib = capi.lib()
+    applied = {(i, j): [] for j in range(nt) for i in range(j, nt)}
+    last_far = 0
+    for kb in range(nt - 1):
+        out = (C.c_int * 10)()
+        assert lib.cugp_potrf_plan(nt, P, near, kb, out) == 0
+        k0, kw, a0, a1, b0, b1, wait, wcol, la0, kfirst = list(out)
+        # panel solve of column kb: every tile of the column is up to date
+        for i in range(kb, nt):
+            assert applied[(i, kb)] == list(range(kb)), (nt, P, near, kb, i, applied[(i, kb)])
+        assert wcol >= 1 and wait == -1 and b1 <= b0
+        far = kb + 1 + wcol                                          # first column outside the near window
+        assert far >= last_far and far <= nt
+        last_far = far
+        if a1 > a0:
+            p = kb // P
+            assert (k0, kw) == (p * P, P) and k0 + kw == kb + 1      # the panel just completed ...
+            assert (a0, a1) == (far, nt)                             # ... goes to everything beyond the window
+            for j in range(a0, a1):
+                for i in range(j, nt):
+                    applied[(i, j)] += list(range(k0, k0 + kw))
+        else:
+            assert far == nt or kb % P != P - 1
+        for j in range(kb + 1, far):
+            ks = list(range(kfirst, kb + 1)) if j >= la0 else [kb]
+            for i in range(j, nt):
+                applied[(i, j)] += ks
+        # the diagonal block factored inside this launch
+        assert applied[(kb + 1, kb + 1)] == list(range(kb + 1)), (nt, P, near, kb, applied[(kb + 1, kb + 1)])
+    for (i, j), ks in applied.items():
+        assert ks == list(range(j)), (nt, P, near, i, j, ks)          # exactly once each, ascending
+
+
+def test_potrf_plan_covers_every_update_exactly_once_in_order():
+    for P in (1, 2, 3, 4, 5, 8):
+        for near in (1, 40, 300, 700, 5000):
+            for nt in list(range(2, 30)) + [40, 63, 64, 79]:
+                _replay_potrf_plan(nt, P, near)
