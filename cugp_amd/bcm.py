@@ -68,6 +68,16 @@ class ShardedBCM:
                 else torch.device("cpu")
         self.comm_device = comm_device
         self._rows = torch.zeros((self.K, 4), dtype=torch.float64, device=comm_device)
+        # RCCL path: the per-expert rows go from the evaluation's result buffer straight into this device tensor
+        # (no fetch / numpy / H2D on the critical path); needs the library-level BCM of this rank's experts
+        self._on_device = (comm_device.type == "cuda" and expert_factory is None and len(self.mine) > 0)
+        if self._on_device and self._group is None:
+            X, y = (np.ascontiguousarray(a, dtype=np.float64) for a in experts[self.mine[0]])
+            for e in self.local.values():
+                e.close()
+            self._group = _gp.BCM([X.shape[0]], X.shape[1], device)
+            self._group.set_expert_data(0, X, y)
+            self.local = {self.mine[0]: self._group.expert(0)}
 
     # BCM::set_BCM_log_hyperparam (BCM.cpp:123-130): every expert gets the same vector
     def set_loghyper(self, hp):
@@ -85,6 +95,12 @@ class ShardedBCM:
 
     def loglik_grad(self):
         """-> (sum_k LL_k, sum_k grad_k, per-expert LL[K]); one collective of K x 4 doubles."""
+        if self._on_device:
+            self._rows.zero_()                    # the other ranks' rows must be exact zeros
+            torch.cuda.current_stream(self.comm_device).synchronize()
+            self._group.loglik_grad_rows_device(self._rows.data_ptr(), self.mine)
+            out = self._allreduce(self._rows).cpu().numpy()
+            return self._ordered_sum(out)
         rows = np.zeros((self.K, 4))
         if self._group is not None:
             rows[self.mine] = self._group.loglik_grad_rows()
@@ -97,6 +113,9 @@ class ShardedBCM:
                 rows[k, 1:] = g
         self._rows.copy_(torch.from_numpy(rows))
         out = self._allreduce(self._rows).cpu().numpy()
+        return self._ordered_sum(out)
+
+    def _ordered_sum(self, out):
         ll, g = 0.0, np.zeros(3)
         for k in range(self.K):                   # expert order, as BCM.cpp:161-197
             ll = ll + out[k, 0]

@@ -69,6 +69,8 @@ SIGNATURES = {
     "cugp_rprop_solve": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, _ip]),
     "cugp_bcm_create": (C.c_int, [C.c_int, _ip, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "cugp_bcm_create_split": (C.c_int, [_dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "cugp_bcm_create_multi": (C.c_int, [C.c_int, _ip, C.c_int, _ip, C.c_int, C.POINTER(C.c_void_p)]),
+    "cugp_bcm_create_split_multi": (C.c_int, [_dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, _ip, C.POINTER(C.c_void_p)]),
     "cugp_bcm_destroy": (C.c_int, [C.c_void_p]),
     "cugp_bcm_num_experts": (C.c_int, [C.c_void_p, _ip]),
     "cugp_bcm_expert": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
@@ -77,6 +79,7 @@ SIGNATURES = {
     "cugp_bcm_get_loghyper": (C.c_int, [C.c_void_p, _dp]),
     "cugp_bcm_loglik_grad": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
     "cugp_bcm_loglik_grad_rows": (C.c_int, [C.c_void_p, _dp]),
+    "cugp_bcm_loglik_grad_rows_device": (C.c_int, [C.c_void_p, C.c_void_p, _ip]),
     "cugp_bcm_predict_partial": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _dp]),
     "cugp_poe_finish": (C.c_int, [_dp, _dp, C.c_int, _dp, _dp]),
     "cugp_bcm_predict": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _dp]),
@@ -85,6 +88,7 @@ SIGNATURES = {
     "cugp_mfma_peak_tflops": (C.c_int, [C.c_int, _dp]),
     "cugp_set_tuning": (C.c_int, [C.c_int, C.c_int]),
     "cugp_bench_la": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
+    "cugp_bench_la_check": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp]),
     "cugp_potrf_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _ip]),
 }
 

@@ -1,4 +1,4 @@
-// bcm.cpp -- product-of-experts ("BCM") over the experts resident on one GPU.
+// bcm.cpp -- product-of-experts ("BCM") over the experts resident on the GPUs of one process.
 //
 // Mirrors class BCM (distributed_gp/BCM.h:2-27, BCM.cpp): K experts, each a full GP on its own rows,
 // the objective is the plain sum of the experts' log-likelihoods / gradients (BCM.cpp:153-198) and
@@ -17,23 +17,35 @@
 #include "../../include/cugp.h"
 #include "group.h"
 
+// the experts of one device: evaluated as one group of shared launches when their shapes allow it
+struct DeviceSet {
+    int device = 0;
+    std::vector<int> idx;            // global expert indices, ascending
+    cugp_group* group = nullptr;     // null: a single expert, or shapes differ
+    bool grouped_now = false;        // the evaluation in flight was enqueued as a group
+};
+
 struct cugp_bcm {
-    cugp_group* group = nullptr;     // all experts in one set of launches (null: one expert, or shapes differ)
-    std::vector<cugp_gp*> experts;
+    std::vector<DeviceSet> sets;     // one per entry of the device list (the same device may be listed twice)
+    std::vector<cugp_gp*> experts;   // global order k = 0..K-1
     std::vector<int> rows;
-    int d = 0, device = 0;
+    int d = 0;
     double hp[3] = {0, 0, 0};
 };
 
 extern "C" {
 
-int cugp_bcm_create(int nexperts, const int* rows, int d, int device, cugp_bcm** out)
+// Experts k = 0..K-1 over the devices of one process: expert k lives on devices[k mod ndev] -- the reference's
+// placement of chunk i on worker i mod W (cuda_scalingdist/cg_solver.cpp:93) -- and one host thread drives all
+// of them: every device's experts are enqueued (one group of shared launches per device) before the first
+// result is read, sums are taken in expert order on the host, so the numbers are those of the single-device
+// BCM bit for bit whatever the device list (distributed_gp/BCM.cpp:153-198).
+int cugp_bcm_create_multi(int ndev, const int* devices, int nexperts, const int* rows, int d, cugp_bcm** out)
 {
-    if (!out || nexperts <= 0 || !rows || d <= 0) return CUGP_ERR_INVALID;
+    if (!out || ndev <= 0 || !devices || nexperts <= 0 || !rows || d <= 0) return CUGP_ERR_INVALID;
     cugp_bcm* b = new (std::nothrow) cugp_bcm;
     if (!b) return CUGP_ERR_NOMEM;
     b->d = d;
-    b->device = device;
     // Common padded size (identity padding) so that the experts can share launches -- unless their row counts
     // differ by more than a tile or ~6 %: then padding the small ones would cost more than it gains.
     int nmax = 0, nmin = rows[0];
@@ -44,22 +56,38 @@ int cugp_bcm_create(int nexperts, const int* rows, int d, int device, cugp_bcm**
     }
     const int tmax = (nmax + 127) / 128, tmin = (nmin + 127) / 128;
     const int pad_to = (tmax - tmin <= (tmin / 16 > 1 ? tmin / 16 : 1)) ? nmax : 0;
+    const int nsets = ndev < nexperts ? ndev : nexperts;
+    b->sets.resize(nsets);
+    for (int s = 0; s < nsets; s++) b->sets[s].device = devices[s];
     for (int k = 0; k < nexperts; k++) {
+        DeviceSet& ds = b->sets[k % nsets];
         cugp_gp* g = nullptr;
-        int rc = cugp_create_padded(rows[k], d, device, pad_to, &g);
+        int rc = cugp_create_padded(rows[k], d, ds.device, pad_to, &g);
         if (rc) { cugp_bcm_destroy(b); return rc; }
         // several experts on one device already fill each other's idle time; the extra streams only cost launches
-        if (nexperts > 1) cugp_set_overlap(g, 0);
+        if (nexperts > nsets) cugp_set_overlap(g, 0);
         b->experts.push_back(g);
         b->rows.push_back(rows[k]);
+        ds.idx.push_back(k);
     }
-    if (nexperts > 1 && cugp_group_create(b->experts.data(), nexperts, &b->group) != CUGP_OK) b->group = nullptr;
+    for (DeviceSet& ds : b->sets) {
+        if (ds.idx.size() < 2) continue;
+        std::vector<cugp_gp*> mine;
+        for (int k : ds.idx) mine.push_back(b->experts[k]);
+        if (cugp_group_create(mine.data(), (int)mine.size(), &ds.group) != CUGP_OK) ds.group = nullptr;
+    }
     *out = b;
     return CUGP_OK;
 }
 
+int cugp_bcm_create(int nexperts, const int* rows, int d, int device, cugp_bcm** out)
+{
+    return cugp_bcm_create_multi(1, &device, nexperts, rows, d, out);
+}
+
 // BCM.cpp:85-110 -- expert k gets rows [k*floor(N/K), ...), the last one also the remainder
-int cugp_bcm_create_split(const double* X, const double* y, int N, int D, int K, int device, cugp_bcm** out)
+int cugp_bcm_create_split_multi(const double* X, const double* y, int N, int D, int K, int ndev, const int* devices,
+                                cugp_bcm** out)
 {
     if (!X || !y || N <= 0 || D <= 0 || K <= 0 || K > N) return CUGP_ERR_INVALID;
     std::vector<int> rows(K), off(K);
@@ -70,7 +98,7 @@ int cugp_bcm_create_split(const double* X, const double* y, int N, int D, int K,
         rows[k] = (k == K - 1) ? (N - start) : part;
         start += part;
     }
-    int rc = cugp_bcm_create(K, rows.data(), D, device, out);
+    int rc = cugp_bcm_create_multi(ndev, devices, K, rows.data(), D, out);
     if (rc) return rc;
     for (int k = 0; k < K; k++) {
         rc = cugp_bcm_set_expert_data(*out, k, X + (size_t)off[k] * D, y + off[k]);
@@ -79,10 +107,15 @@ int cugp_bcm_create_split(const double* X, const double* y, int N, int D, int K,
     return CUGP_OK;
 }
 
+int cugp_bcm_create_split(const double* X, const double* y, int N, int D, int K, int device, cugp_bcm** out)
+{
+    return cugp_bcm_create_split_multi(X, y, N, D, K, 1, &device, out);
+}
+
 int cugp_bcm_destroy(cugp_bcm* b)
 {
     if (!b) return CUGP_OK;
-    cugp_group_destroy(b->group);
+    for (DeviceSet& ds : b->sets) cugp_group_destroy(ds.group);
     for (cugp_gp* g : b->experts) cugp_destroy(g);
     delete b;
     return CUGP_OK;
@@ -126,31 +159,80 @@ int cugp_bcm_get_loghyper(const cugp_bcm* b, double hp[3])
     return CUGP_OK;
 }
 
-// rows[k] = {LL_k, g_k[0..2]} for every expert of this device (what a multi-device BCM all-reduces)
+// all experts of all devices in flight (a group of shared launches per device where possible, else one stream
+// per expert) before anything is read back
+static int bcm_enqueue_all(cugp_bcm* b)
+{
+    for (DeviceSet& ds : b->sets) {
+        ds.grouped_now = false;
+        if (ds.group) {
+            const int rc = cugp_group_enqueue(ds.group, 1);
+            if (rc == CUGP_OK) { ds.grouped_now = true; continue; }
+            if (rc != CUGP_ERR_INVALID) return rc;       // INVALID: not possible as a group right now
+        }
+        for (int k : ds.idx) {
+            const int rc = cugp_loglik_grad_enqueue(b->experts[k], 1);
+            if (rc) return rc;
+        }
+    }
+    return CUGP_OK;
+}
+
+// rows[k] = {LL_k, g_k[0..2]} for every expert of this handle, k in global order (what a multi-process BCM
+// all-reduces across ranks)
 int cugp_bcm_loglik_grad_rows(cugp_bcm* b, double* rows)
 {
     if (!b || !rows) return CUGP_ERR_INVALID;
-    const size_t K = b->experts.size();
-    std::vector<double> lk(K), gk3(3 * K);
-    bool grouped = false;
-    if (b->group) {
-        const int rc = cugp_group_eval(b->group, 1, lk.data(), gk3.data());
-        if (rc == CUGP_OK) grouped = true;
-        else if (rc != CUGP_ERR_INVALID) return rc;      // INVALID: not possible as a group right now
-    }
-    if (!grouped) {
-        for (cugp_gp* e : b->experts) {                  // all experts in flight before the first fetch
-            int rc = cugp_loglik_grad_enqueue(e, 1);
-            if (rc) return rc;
+    int rc = bcm_enqueue_all(b);
+    if (rc) return rc;
+    std::vector<double> lk, gk3;
+    for (DeviceSet& ds : b->sets) {
+        const size_t n = ds.idx.size();
+        lk.assign(n, 0.0);
+        gk3.assign(3 * n, 0.0);
+        if (ds.grouped_now) {
+            if ((rc = cugp_group_fetch(ds.group, lk.data(), gk3.data()))) return rc;
+        } else {
+            for (size_t i = 0; i < n; i++)
+                if ((rc = cugp_loglik_grad_fetch(b->experts[ds.idx[i]], &lk[i], &gk3[3 * i]))) return rc;
         }
-        for (size_t k = 0; k < K; k++) {
-            int rc = cugp_loglik_grad_fetch(b->experts[k], &lk[k], &gk3[3 * k]);
-            if (rc) return rc;
+        for (size_t i = 0; i < n; i++) {
+            const size_t k = (size_t)ds.idx[i];
+            rows[4 * k] = lk[i];
+            for (int j = 0; j < 3; j++) rows[4 * k + 1 + j] = gk3[3 * i + j];
         }
     }
-    for (size_t k = 0; k < K; k++) {
-        rows[4 * k] = lk[k];
-        for (int i = 0; i < 3; i++) rows[4 * k + 1 + i] = gk3[3 * k + i];
+    return CUGP_OK;
+}
+
+// The same payload left ON THE DEVICE for a collective that never touches the host (RCCL all-reduce over
+// xGMI in cugp_amd/bcm.py): row slot[k] of dev_rows ([.][4] doubles, device memory of the handle's first device,
+// e.g. a zeroed buffer with one row per expert of the WHOLE model) receives {LL_k, g_k} of local expert k.
+// Returns when the rows are in place (the evaluation itself is the wait); single-device handles only.
+int cugp_bcm_loglik_grad_rows_device(cugp_bcm* b, double* dev_rows, const int* slot)
+{
+    if (!b || !dev_rows || !slot) return CUGP_ERR_INVALID;
+    if (b->sets.size() != 1) return CUGP_ERR_INVALID;
+    int rc = bcm_enqueue_all(b);
+    if (rc) return rc;
+    DeviceSet& ds = b->sets[0];
+    const size_t n = ds.idx.size();
+    if (ds.grouped_now) {
+        const double* dout = nullptr;
+        void* stream = nullptr;
+        if ((rc = cugp_group_device_results(ds.group, &dout, &stream))) return rc;
+        for (size_t i = 0; i < n; i++)
+            if ((rc = cugp_copy_device_row(dev_rows + 4 * (size_t)slot[ds.idx[i]], dout + 8 * i, stream))) return rc;
+        std::vector<double> lk(n), gk3(3 * n);
+        return cugp_group_fetch(ds.group, lk.data(), gk3.data());     // waits for the stream: rows are in place
+    }
+    for (size_t i = 0; i < n; i++) {
+        cugp_gp* e = b->experts[ds.idx[i]];
+        if ((rc = cugp_copy_result_row(e, dev_rows + 4 * (size_t)slot[ds.idx[i]]))) return rc;
+    }
+    for (size_t i = 0; i < n; i++) {
+        double l, g3[3];
+        if ((rc = cugp_loglik_grad_fetch(b->experts[ds.idx[i]], &l, g3))) return rc;
     }
     return CUGP_OK;
 }

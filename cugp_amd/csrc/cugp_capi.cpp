@@ -1188,6 +1188,13 @@ int cugp_test_gemm_nt(int m, int n, int k, const double* A, const double* B, dou
 // 2 K^-1 = L^-T L^-1 from the triangular inverse, 3 the three together.  ms = best of `reps`.
 int cugp_bench_la(int op, int n, int device, int reps, double* ms)
 {
+    return cugp_bench_la_check(op, n, device, reps, ms, nullptr);
+}
+
+// the same, and (ops 0 and 3) the log-determinant of the matrix from the factor it timed, so a test can tell
+// that the timed launches produced the right factor
+int cugp_bench_la_check(int op, int n, int device, int reps, double* ms, double* logdet)
+{
     if (!ms || n <= 0 || op < 0 || op > 4 || reps <= 0) return CUGP_ERR_INVALID;
     cugp_gp* g = nullptr;
     const int d = 4;
@@ -1219,6 +1226,16 @@ int cugp_bench_la(int op, int n, int device, int reps, double* ms)
         float t = 0;
         if (e == hipSuccess) e = hipEventElapsedTime(&t, e0, e1);
         if (r > 0 && t < best) best = t;                          // first round warms up
+    }
+    if (logdet && rc == CUGP_OK && e == hipSuccess) {
+        *logdet = NAN;
+        if (op == 0 || op == 3) {                                     // 2 * sum of the diagonal blocks' shares
+            std::vector<double> part(g->nt);
+            e = hipMemcpy(part.data(), g->dlogdet, (size_t)g->nt * sizeof(double), hipMemcpyDeviceToHost);
+            double acc = 0.0;
+            for (double v : part) acc += v;
+            *logdet = 2.0 * acc;
+        }
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     cugp_destroy(g);
@@ -1262,6 +1279,7 @@ struct cugp_group {
     bool tab_valid = false;
     hipGraphExec_t gexec[2] = {nullptr, nullptr};
     unsigned gepoch[2] = {0, 0};
+    bool pending = false, pending_grad = false;   // an evaluation is enqueued and not yet fetched
 };
 
 int cugp_group_create(cugp_gp* const* experts, int k, cugp_group** out)
@@ -1306,13 +1324,18 @@ void cugp_group_destroy(cugp_group* gr)
     delete gr;
 }
 
-int cugp_group_eval(cugp_group* gr, int want_grad, double* ll, double* g)
+// Enqueue one evaluation of all experts of the group on the lead expert's stream(s); results stay on the device
+// (ctx.dout, [k][8]) and travel to the pinned ctx.hout behind it.  cugp_group_fetch waits and reads them.
+int cugp_group_enqueue(cugp_group* gr, int want_grad)
 {
-    if (!gr || !ll) return CUGP_ERR_INVALID;
+    if (!gr) return CUGP_ERR_INVALID;
     cugp_gp* lead = gr->experts[0];
     const int k = (int)gr->experts.size(), nt = lead->nt;
     int rc;
+    if (gr->pending) return fail(CUGP_ERR_INVALID, "cugp_group_enqueue: an evaluation is already in flight");
     if (nt > g_tune[TUNE_GROUP_MAX_TILES]) return CUGP_ERR_INVALID;
+    // the batched step kernel puts its workgroups on gridDim.y (65535 at most): larger experts go one by one
+    if ((long long)nt * (nt + 1) / 2 + 16 > 65535) return CUGP_ERR_INVALID;
     for (cugp_gp* e : gr->experts) {
         if (!e->have_data || e->prof != 0 || pipe_block(e, want_grad != 0) != 0) return CUGP_ERR_INVALID;   // (experts of a BCM have their own overlap off)
         if (e->hp[0] != lead->hp[0] || e->hp[1] != lead->hp[1] || e->hp[2] != lead->hp[2]) return CUGP_ERR_INVALID;
@@ -1325,6 +1348,8 @@ int cugp_group_eval(cugp_group* gr, int want_grad, double* ll, double* g)
         if (want_grad && (rc = ensure_inverse_bufs(e))) return rc;
         if (!had) gr->tab_valid = false;
     }
+    if (const int pe = prepare_kernels())
+        return fail(CUGP_ERR_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)", (hipError_t)pe);
     if (!gr->tab_valid) {
         std::vector<ExpertPtrs> tab(k);
         for (int i = 0; i < k; i++) {
@@ -1342,12 +1367,12 @@ int cugp_group_eval(cugp_group* gr, int want_grad, double* ll, double* g)
     gr->ctx.overlap = g_tune[TUNE_GROUP_OVERLAP] != 0;
     lead->grp = &gr->ctx;
     const int gi = want_grad ? 1 : 0;
-    // (with the hand-over the sequence spans three streams: enqueued launch by launch, not replayed)
-    if (g_tune[TUNE_GRAPHS] != 0 && nt <= GRAPH_MAX_TILES && pipe_block(lead, want_grad != 0) == 0) {
+    // (with the hand-over the sequence spans several streams: enqueued launch by launch, not replayed)
+    if (g_tune[TUNE_GRAPHS] != 0 && nt <= GRAPH_MAX_TILES && pipe_block(lead, want_grad != 0) == 0 &&
+        panel_width(lead) == 1) {
         if (!gr->gexec[gi] || gr->gepoch[gi] != g_cfg_epoch) {
             if (gr->gexec[gi]) (void)hipGraphExecDestroy(gr->gexec[gi]);
             gr->gexec[gi] = nullptr;
-            prepare_kernels();
             hipGraph_t graph_obj = nullptr;
             hipError_t e = hipStreamBeginCapture(lead->stream, hipStreamCaptureModeThreadLocal);
             if (e != hipSuccess) { lead->grp = nullptr; return fail(CUGP_ERR_DEVICE, "hipStreamBeginCapture", e); }
@@ -1370,7 +1395,21 @@ int cugp_group_eval(cugp_group* gr, int want_grad, double* ll, double* g)
     }
     lead->grp = nullptr;
     if (rc) return rc;
+    gr->pending = true;
+    gr->pending_grad = want_grad != 0;
+    return CUGP_OK;
+}
+
+int cugp_group_fetch(cugp_group* gr, double* ll, double* g)
+{
+    if (!gr || !ll) return CUGP_ERR_INVALID;
+    if (!gr->pending) return fail(CUGP_ERR_INVALID, "cugp_group_fetch: nothing enqueued");
+    cugp_gp* lead = gr->experts[0];
+    const int k = (int)gr->experts.size();
+    int rc;
+    if ((rc = use_device(lead))) return rc;
     HIPCHK(hipStreamSynchronize(lead->stream));
+    gr->pending = false;
     for (int i = 0; i < k; i++) {
         cugp_gp* e = gr->experts[i];
         const double* h = gr->ctx.hout + (size_t)i * 8;
@@ -1379,7 +1418,7 @@ int cugp_group_eval(cugp_group* gr, int want_grad, double* ll, double* g)
         e->last_logdet = h[5];
         e->factor_valid = true;
         ll[i] = h[0];
-        if (want_grad) {
+        if (gr->pending_grad) {
             for (int j = 0; j < 3; j++) {
                 e->last_g[j] = h[1 + j];
                 if (g) g[3 * i + j] = h[1 + j];
@@ -1387,6 +1426,37 @@ int cugp_group_eval(cugp_group* gr, int want_grad, double* ll, double* g)
             e->inverse_valid = true;
         }
     }
+    return CUGP_OK;
+}
+
+int cugp_copy_device_row(double* dst, const double* src, void* stream)
+{
+    HIPCHK(hipMemcpyAsync(dst, src, 4 * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return CUGP_OK;
+}
+
+int cugp_copy_result_row(cugp_gp* g, double* dst)
+{
+    if (!g || !dst || !g->pending) return CUGP_ERR_INVALID;
+    int rc;
+    if ((rc = use_device(g))) return rc;
+    return cugp_copy_device_row(dst, g->dout, g->stream);
+}
+
+int cugp_group_eval(cugp_group* gr, int want_grad, double* ll, double* g)
+{
+    if (!gr || !ll) return CUGP_ERR_INVALID;
+    const int rc = cugp_group_enqueue(gr, want_grad);
+    return rc ? rc : cugp_group_fetch(gr, ll, g);
+}
+
+// device side of the results of the evaluation in flight: [k][8] doubles, row i = {LL, g0, g1, g2, ...} of expert i,
+// valid once everything enqueued on *stream so far has run
+int cugp_group_device_results(cugp_group* gr, const double** dout, void** stream)
+{
+    if (!gr || !dout || !stream) return CUGP_ERR_INVALID;
+    *dout = gr->ctx.dout;
+    *stream = (void*)gr->experts[0]->stream;
     return CUGP_OK;
 }
 

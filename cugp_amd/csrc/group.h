@@ -16,4 +16,13 @@ void cugp_group_destroy(cugp_group* gr);
 // Returns CUGP_ERR_INVALID without touching anything when the experts cannot be evaluated as a group right now
 // (different hyper-parameters, profiling on, missing data): the caller then evaluates them one by one.
 int cugp_group_eval(cugp_group* gr, int want_grad, double* ll, double* g);
+// the same in two halves, so the groups of several devices are all in flight before the first result is read
+int cugp_group_enqueue(cugp_group* gr, int want_grad);
+int cugp_group_fetch(cugp_group* gr, double* ll, double* g);
+// device copy of the results of the evaluation in flight ([k][8] doubles: LL, g0, g1, g2, ...) and the stream
+// (hipStream_t) they are ordered on -- for a reduction that stays on the device (RCCL all-reduce)
+int cugp_group_device_results(cugp_group* gr, const double** dout, void** stream);
+// 4 doubles device -> device on `stream` (hipStream_t); the result row of the evaluation a single expert has in flight
+int cugp_copy_device_row(double* dst, const double* src, void* stream);
+int cugp_copy_result_row(cugp_gp* gp, double* dst);
 }  // extern "C"

@@ -189,30 +189,34 @@ class Covsum:
         check(capi.lib().cugp_get_phase_ms(self._h, ptr(ms)))
         return dict(zip(("kbuild", "potrf", "trtri", "lauum", "tail", "total"), ms.tolist()))
 
-    def kernel_stats(self, reset=False):
+    def kernel_stats(self, reset=False, kind=0):
+        """HIP-event timings of the Cholesky trailing updates: kind 0 = k_syrk_step, 1 = k_syrk_wide."""
         s, n, f = C.c_double(), C.c_longlong(), C.c_double()
-        check(capi.lib().cugp_get_kernel_stats(self._h, C.byref(s), C.byref(n), C.byref(f), 1 if reset else 0))
+        check(capi.lib().cugp_get_kernel_stats_kind(self._h, int(kind), C.byref(s), C.byref(n), C.byref(f),
+                                                    1 if reset else 0))
         return {"sum_ms": s.value, "launches": n.value, "flop": f.value}
 
 
 class BCM:
-    """Experts resident on ONE GPU (class BCM, distributed_gp/BCM.h).  `BCM.split` reproduces the
-    reference constructor's row partition (BCM.cpp:85-110)."""
+    """Experts resident on the GPU(s) of this process (class BCM, distributed_gp/BCM.h).  `devices` lists the
+    GPUs (expert k on devices[k mod len], cg_solver.cpp:93; default: the one `device`).  `BCM.split` reproduces
+    the reference constructor's row partition (BCM.cpp:85-110)."""
 
-    def __init__(self, rows, d, device=0):
+    def __init__(self, rows, d, device=0, devices=None):
         rows = np.ascontiguousarray(rows, dtype=np.int32)
-        self.rows, self.d, self.device = rows.tolist(), int(d), int(device)
+        devs = np.ascontiguousarray([device] if devices is None else list(devices), dtype=np.int32)
+        self.rows, self.d, self.device, self.devices = rows.tolist(), int(d), int(devs[0]), devs.tolist()
         self._h = C.c_void_p()
-        check(capi.lib().cugp_bcm_create(len(self.rows), rows.ctypes.data_as(capi._ip), self.d, self.device,
-                                         C.byref(self._h)))
+        check(capi.lib().cugp_bcm_create_multi(len(self.devices), devs.ctypes.data_as(capi._ip), len(self.rows),
+                                               rows.ctypes.data_as(capi._ip), self.d, C.byref(self._h)))
 
     @classmethod
-    def split(cls, X, y, K, device=0):
+    def split(cls, X, y, K, device=0, devices=None):
         X, y = f64(X), f64(y)
         N, D = X.shape
         part = N // K
         rows = [part] * (K - 1) + [N - part * (K - 1)]
-        b = cls(rows, D, device)
+        b = cls(rows, D, device, devices)
         off = 0
         for k in range(K):
             b.set_expert_data(k, X[off: off + rows[k]], y[off: off + rows[k]])
@@ -258,12 +262,19 @@ class BCM:
         check(capi.lib().cugp_bcm_loglik_grad_rows(self._h, ptr(rows)))
         return rows
 
+    def loglik_grad_rows_device(self, dev_rows_ptr, slots):
+        """Leave every local expert's (LL_k, gradient) row in DEVICE memory: row slots[k] of the [., 4] buffer at
+        dev_rows_ptr (same GPU) -- the payload of an all-reduce that never touches the host."""
+        slots = np.ascontiguousarray(slots, dtype=np.int32)
+        check(capi.lib().cugp_bcm_loglik_grad_rows_device(self._h, C.c_void_p(dev_rows_ptr),
+                                                          slots.ctypes.data_as(capi._ip)))
+
     def expert(self, k):
         """Borrowed view of expert k as a Covsum-like object (prediction, intermediates); owned by the BCM."""
         h = C.c_void_p()
         check(capi.lib().cugp_bcm_expert(self._h, int(k), C.byref(h)))
         e = Covsum.__new__(Covsum)
-        e.n, e.d, e.device, e._h, e._data_key = self.rows[k], self.d, self.device, h, None
+        e.n, e.d, e.device, e._h, e._data_key = self.rows[k], self.d, self.devices[k % len(self.devices)], h, None
         e.close = lambda: None                    # not ours to destroy
         return e
 

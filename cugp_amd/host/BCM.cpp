@@ -16,14 +16,29 @@ void must(int rc, const char *what)
 }
 }  // namespace
 
-BCM::BCM(double **inp, double *out, int N, int D, int K) : BCM(inp, out, N, D, K, 0) {}
+namespace {
+std::vector<int> all_devices(int K)
+{
+    int cnt = 0;
+    must(cugp_device_count(&cnt), "cugp_device_count");
+    if (cnt > K) cnt = K;
+    std::vector<int> d(cnt > 0 ? cnt : 1, 0);
+    for (int i = 0; i < (int)d.size(); i++) d[i] = i;
+    return d;
+}
+}  // namespace
 
-BCM::BCM(double **inp, double *out, int N, int D, int K, int device)
+BCM::BCM(double **inp, double *out, int N, int D, int K)
+    : BCM(inp, out, N, D, K, all_devices(K).data(), (int)all_devices(K).size()) {}
+
+BCM::BCM(double **inp, double *out, int N, int D, int K, int device) : BCM(inp, out, N, D, K, &device, 1) {}
+
+BCM::BCM(double **inp, double *out, int N, int D, int K, const int *devices, int ndev)
     : handle(nullptr), num_experts(K), dim(D), log_hyper_bcm{0, 0, 0}
 {
     std::vector<double> flat((size_t)N * D);
     for (int i = 0; i < N; i++) memcpy(&flat[(size_t)i * D], inp[i], D * sizeof(double));
-    must(cugp_bcm_create_split(flat.data(), out, N, D, K, device, &handle), "BCM");
+    must(cugp_bcm_create_split_multi(flat.data(), out, N, D, K, ndev, devices, &handle), "BCM");
 }
 
 BCM::~BCM()

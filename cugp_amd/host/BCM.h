@@ -1,7 +1,9 @@
 // BCM.h -- drop-in for the reference's class BCM (distributed_gp/BCM.h:2-27) over the C-ABI.
-// K experts on contiguous row ranges of one dataset (BCM.cpp:85-110), all resident on one GPU and
-// evaluated concurrently; sums in expert order.  For experts spread over several GPUs see
-// cugp_amd/bcm.py (one process per GPU, RCCL all-reduce of the same per-expert rows).
+// K experts on contiguous row ranges of one dataset (BCM.cpp:85-110).  The default constructor spreads them
+// over ALL GPUs the process sees (expert k on GPU k mod G, the reference's chunk i -> worker i mod W,
+// cuda_scalingdist/cg_solver.cpp:93): one host thread drives every GPU (cugp_bcm_create_multi), sums are taken in
+// expert order, so the numbers do not depend on the GPU count.  One process per GPU with an RCCL all-reduce of
+// the same per-expert rows: cugp_amd/bcm.py.
 #ifndef CUGP_HOST_BCM_H
 #define CUGP_HOST_BCM_H
 
@@ -15,7 +17,8 @@ private:
 
 public:
     BCM(double **inp, double *out, int N, int D, int K);
-    BCM(double **inp, double *out, int N, int D, int K, int device);
+    BCM(double **inp, double *out, int N, int D, int K, int device);                       // one given GPU
+    BCM(double **inp, double *out, int N, int D, int K, const int *devices, int ndev);     // a given list of GPUs
     ~BCM();
     BCM(const BCM &) = delete;              // the reference passes BCM by value relying on an empty destructor
     BCM &operator=(const BCM &) = delete;   // (distributed_ver1.cpp:13,285); take it by reference instead

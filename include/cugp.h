@@ -146,6 +146,12 @@ int cugp_rprop_solve(cugp_gp *gp, int iters, double *trace, int trace_cap, int *
  *                         sum_k 1/v_k and sum_k mu_k/v_k (BCM.cpp:45-62); cugp_poe_finish turns (all-reduced)
  *                         sums into mean / variance */
 int cugp_bcm_create(int nexperts, const int *rows, int d, int device, cugp_bcm **out);
+/* the same over several GPUs of ONE process: expert k on devices[k mod ndev] (chunk i -> worker i mod W,
+ * cuda_scalingdist/cg_solver.cpp:93), all devices in flight at once, sums in expert order on the host -- the
+ * C++ class BCM (cugp_amd/host/BCM.h) uses the whole node through this.  Listing a device twice is allowed. */
+int cugp_bcm_create_multi(int ndev, const int *devices, int nexperts, const int *rows, int d, cugp_bcm **out);
+int cugp_bcm_create_split_multi(const double *X, const double *y, int N, int D, int K, int ndev, const int *devices,
+                                cugp_bcm **out);
 int cugp_bcm_create_split(const double *X, const double *y, int N, int D, int K, int device, cugp_bcm **out);
 int cugp_bcm_destroy(cugp_bcm *b);
 int cugp_bcm_num_experts(const cugp_bcm *b, int *k);
@@ -157,6 +163,9 @@ int cugp_bcm_loglik_grad(cugp_bcm *b, double *ll, double g[3], double *per_exper
 /* rows[k][4] = {LL_k, dLL_k/dtheta (as gradients of -LL)} per expert of this device: the payload a multi-device
  * BCM sums across devices (the two gathers of cuda_scalingdist/cg_solver.cpp:72-213 in one buffer) */
 int cugp_bcm_loglik_grad_rows(cugp_bcm *b, double *rows);
+/* the same rows left in DEVICE memory for a collective that stays on the device (RCCL all-reduce): row slot[k] of
+ * dev_rows ([.][4] doubles on the handle's device) receives local expert k's {LL, g}; single-device handles */
+int cugp_bcm_loglik_grad_rows_device(cugp_bcm *b, double *dev_rows, const int *slot);
 int cugp_bcm_predict_partial(cugp_bcm *b, const double *Xt, int nt, double *sum_prec, double *sum_prec_mean);
 int cugp_poe_finish(const double *sum_prec, const double *sum_prec_mean, int nt, double *mean, double *var);
 int cugp_bcm_predict(cugp_bcm *b, const double *Xt, int nt, double *mean, double *var); /* BCM.cpp:64-83 */
@@ -169,6 +178,8 @@ int cugp_mfma_peak_tflops(int device, double *tflops);
  * cholesky_cu_solver.cpp), 1 triangular inverse of the factor (tmi_cu_solver.cpp), 2 K^-1 from it, 3 all three,
  * 4 plain C = K K^T with uniform tiles (cublas_matrix_multiply.cpp) */
 int cugp_bench_la(int op, int n, int device, int reps, double *ms);
+/* the same, and for ops 0 and 3 log|K| taken from the factor the timed launches produced (NaN otherwise) */
+int cugp_bench_la_check(int op, int n, int device, int reps, double *ms, double *logdet);
 int cugp_set_tuning(int key, int value);     /* launch-shape thresholds (kernels.h TUNE_*), for A/B runs */
 /* the launches of step kb of the two-speed Cholesky with panels of P steps and a near window of about `near_tiles`
  * tiles (pure arithmetic, no device): out = {wide k0, wide k tiles, wide columns [a0,a1) then [b0,b1), panel whose

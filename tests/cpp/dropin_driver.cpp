@@ -61,6 +61,13 @@ int main(int argc, char **argv)
         kernelobj.compute_K_train(X, Krows.data());
         pv("K_row5", Krows[5], ntrain);
         printf("\"param_dim\": %d,\n", kernelobj.get_param_dim());
+        // the second optimiser of the class (serial_gp.cpp:70 keeps the call commented out beside cg_solve)
+        kernelobj.set_loghyperparam(inithypervalues);
+        kernelobj.rprop_solve(X, y, false);
+        pv("rprop_final_hp", kernelobj.get_loghyperparam(), 3);
+        printf("\"rprop_final_ll\": %.17g,\n", kernelobj.compute_loglikelihood(X, y));
+        kernelobj.compute_squared_dist(X, 2.5);
+        pv("sqdist_row3", kernelobj.squared_dist().data() + (size_t)3 * ntrain, ntrain);
     }
     {   // ---- class BCM, as distributed_ver1.cpp uses it ----
         double inithypervalues[] = {1.5, 1.5, 1.5};
@@ -90,8 +97,11 @@ int main(int argc, char **argv)
         pv("api_grad", g, 3);
         cg_solve(argv[0]);
         pv("api_cg_final_hp", get_loghyperparam(), 3, true);
+        printf("}\n");
+        // cuda_src/main.cpp:197: rows [numtrain, numtrain+numtest) of the same file are the test set; prints NLPP
+        set_loghyper_eigen(init);
+        testing_phase(ntrain, ntest);
         destruct_cublas_cusoler();
     }
-    printf("}\n");
     return 0;
 }

@@ -35,7 +35,9 @@ def test_cpp_dropin_driver(tmp_path, si128, golden_si128, oracle):
     txt = out.stdout
     js = txt[txt.index("{"):]
     js = re.sub(r"\n+ PLEASE-SEE 3[^\n]*\n+", "\n", js)
-    r = json.loads(js)
+    tail = js[js.rindex("}") + 1:]
+    r = json.loads(js[: js.rindex("}") + 1])
+    nlpp_api = float(re.search(r"NLPP = ([-+.\deE]+)", tail).group(1))        # testing_phase prints it
 
     o = oracle
     Xtr, ytr, Xt = Xall[:ntrain], yall[:ntrain], Xall[ntrain:]
@@ -52,6 +54,13 @@ def test_cpp_dropin_driver(tmp_path, si128, golden_si128, oracle):
     Ko = o.K_train(Xtr, r["cg_final_hp"])
     assert np.allclose(r["K_row5"], Ko[5], rtol=1e-12, atol=1e-14)
     assert r["param_dim"] == 2
+    # rprop_solve (covkernel.cpp:337-402) through the class, compute_squared_dist, testing_phase through surface B
+    rf, _ = o.rprop_solve(Xtr, ytr, hp)
+    assert np.allclose(r["rprop_final_hp"], rf, atol=5e-5)
+    assert abs(r["rprop_final_ll"] - o.loglik(Xtr, ytr, rf)) <= 1e-5
+    So = o.sqdist(Xtr, 2.5)
+    assert np.allclose(r["sqdist_row3"], So[3], rtol=1e-14, atol=0)
+    assert abs(nlpp_api - o.nlpp(yall[ntrain:], mo, vo)) <= 1e-8
     b = o.bcm(Xtr, ytr, 4, hp)
     assert abs(r["bcm_ll"] - b.loglik()[0]) <= 1e-8 * abs(r["bcm_ll"])
     assert np.allclose(r["bcm_grad"], b.grad(), rtol=1e-7, atol=1e-7)
