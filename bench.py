@@ -13,8 +13,10 @@ With N ranks every rank owns one N=8192 expert (BCM sharding: experts are indepe
 and the per-evaluation exchange is one all-reduce of K x 4 doubles over RCCL.
 
 Rank 0 prints ONE JSON line; besides the driver's contract it carries
-  roofline     the Cholesky trailing update (fp64 MFMA SYRK), HIP-event timed per launch in the timed region
-  cpu_baseline the serial CPU restatement of cpp_serial_gp (oracle/, 1 thread) on a bounded sample
+  roofline        the Cholesky trailing update (fp64 MFMA SYRK), HIP-event timed per launch in the timed region
+  roofline_kbuild the SE-kernel build: bytes written / HIP-event time of its launch against the HBM peak
+  cpu_baseline    the serial CPU restatement of cpp_serial_gp (oracle/, 1 thread) on a bounded sample, next to
+                  what the reference's own code, compiled unmodified, needed for the full-size evaluation
 """
 import argparse
 import json
@@ -33,6 +35,8 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 N_METRIC, D_METRIC = 8192, 10
 HP0 = np.array([np.log(3.0), 0.0, np.log(0.1)])      # non-degenerate point: K is dense, cond ~ 1e3
 MFMA_F64_PEAK_TFLOPS = 78.6                          # MI355X dense fp64 matrix peak (spec)
+HBM_PEAK_GBS = 8000.0                                # MI355X HBM3E (MI355X_MICROARCH.md)
+PMC_SUMMARY = "profiles/r02_pmc_summary.json"        # rocprofv3 --pmc passes of this command (tools/pmc.sh)
 
 
 def synth(n, d, seed):
@@ -55,11 +59,22 @@ def cpu_baseline(n_sample, n_full, d):
     t2 = time.perf_counter()
     sec = t2 - t0
     scale = (n_full / n_sample) ** 3                  # flop-proportional; flatters the CPU (its measured exponent is >3)
+    ref_s = None                                      # the reference compiled unmodified, full size, build container
+    try:                                              # (tests/golden/make_golden.py --big 8192: data, not code)
+        with open(os.path.join(ROOT, "tests", "golden", "golden_big_8192.json")) as f:
+            c = json.load(f)["cases"]["siproper_8192"]
+        if n_full == N_METRIC:
+            ref_s = c["t_ll_s"] + c["t_grad_s"]
+    except Exception:
+        ref_s = None
     return {
         "value": 1.0 / (sec * scale), "unit": "evals/s", "cores": 1, "kind": "port",
         "sample": "LL+grad on the first %d rows of the same synthetic workload: %.2f s (LL %.2f s, grad %.2f s); "
                   "scaled to N=%d by (N/n)^3" % (n_sample, sec, t1 - t0, t2 - t1, n_full),
         "ll_sample": ll, "grad_sample": [float(v) for v in g],
+        "reference_compiled_s": ref_s,
+        "reference_compiled_note": "cpp_serial_gp compiled from the reference's sources (oracle/Makefile), LL + gradient "
+                                   "on siproper_9192 rows 0..8191, one core of the build container" if ref_s else None,
     }
 
 
@@ -91,9 +106,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d (WORLD_SIZE is %d)"
+                         % (args.gpus, args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     if args.single_device:
@@ -106,6 +120,7 @@ def main():
                                     device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)   # RCCL saw all N ranks
 
     from cugp_amd.bcm import ShardedBCM
 
@@ -116,6 +131,8 @@ def main():
         if k % world == rank:
             experts[k] = synth(args.n, args.d, 15618 + k)
     bcm = ShardedBCM(experts, rank=rank, world=world, device=local_rank)
+    if not bcm.local and strong and K < world:
+        pass                                          # more ranks than experts: this rank only takes part in the collectives
     timed_launches = len(bcm.local) == 1              # per-launch HIP events: the single-expert (metric) workload;
     for e in bcm.local.values():                      # several experts per GPU share launches and are not timed singly
         if timed_launches:
@@ -137,7 +154,8 @@ def main():
         step(i)
     if timed_launches:
         first_e = next(iter(bcm.local.values()))
-        first_e.kernel_stats(reset=True)
+        first_e.kernel_stats(reset=True, kind=0)
+        first_e.kernel_stats(reset=True, kind=1)
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -149,22 +167,25 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
-    first = next(iter(bcm.local.values()))
-    ks = first.kernel_stats() if timed_launches else {"launches": 0}
-    ph = first.phase_ms() if timed_launches else {"potrf": float("nan")}
+    first = next(iter(bcm.local.values()), None)      # None: a rank that owns no expert
+    ks = first.kernel_stats(kind=0) if timed_launches else {"launches": 0}
+    kw = first.kernel_stats(kind=1) if timed_launches else {"launches": 0}
+    ph = first.phase_ms() if timed_launches else {"potrf": float("nan"), "kbuild": float("nan")}
     npad = -(-args.n // 128) * 128
 
     # Outside the timed region: the same kernel with the chip to itself.  In the timed region the inverse blocks
     # run beside the factorisation on other streams, so a trailing-update launch shares the CUs and its duration
     # is not a statement about the kernel alone; eight more evaluations with the overlap off give that number.
-    iso = iso_ph = None
+    iso = iso_ph = iso_w = None
     if rank == 0 and len(bcm.local) == 1 and args.overlap:
         first.set_overlap(False)
-        first.kernel_stats(reset=True)
+        first.kernel_stats(reset=True, kind=0)
+        first.kernel_stats(reset=True, kind=1)
         for i in range(8):                        # level-2 profiling times every 8th launch, rotating
             first.set_loghyperparam(HP0 + 1e-3 * ((i % 7) - 3))
             first.loglik_grad()
-        iso = first.kernel_stats()
+        iso = first.kernel_stats(kind=0)
+        iso_w = first.kernel_stats(kind=1)
         iso_ph = first.phase_ms()
         first.set_overlap(True)
 
@@ -187,30 +208,55 @@ def main():
             "phase_ms_last": {k: round(v, 4) for k, v in ph.items()},
             "ll_last": ll, "grad_last": [float(v) for v in g],
         }
-        traffic = None      # HBM bytes per launch from the PMC passes committed under profiles/ (tools/pmc.sh,
-        try:                # tools/pmc_summary.py: 2 x FETCH_SIZE + WRITE_SIZE, per launch); not collectable in-process
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")) as f:
-                if args.n == N_METRIC:
-                    traffic = json.load(f)["kernels"]["k_syrk_step"]["hbm_bytes_per_launch"]
+        # HBM bytes per launch from the rocprofv3 --pmc passes of this same command, committed under profiles/
+        # (tools/pmc.sh, tools/pmc_summary.py: 2 x FETCH_SIZE + WRITE_SIZE per launch; counters cannot be read
+        # in-process, so the figure is a committed measurement and says where it comes from)
+        pmc = {}
+        try:
+            with open(os.path.join(ROOT, PMC_SUMMARY)) as f:
+                pmc = json.load(f)["kernels"] if args.n == N_METRIC else {}
         except Exception:
-            traffic = None
+            pmc = {}
+
+        def roof(name, what, st, iso_st):
+            ach = st["flop"] / (st["sum_ms"] * 1e-3) / 1e12
+            r = {"kernel": what, "bound": "mfma", "achieved": ach, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                 "frac": ach / MFMA_F64_PEAK_TFLOPS,
+                 "traffic": pmc.get(name, {}).get("hbm_bytes_per_launch"),
+                 "traffic_source": PMC_SUMMARY if name in pmc else None,
+                 "launches": int(st["launches"]), "avg_launch_us": 1e3 * st["sum_ms"] / st["launches"],
+                 "algorithmic_flop_per_launch": st["flop"] / st["launches"]}
+            if iso_st and iso_st["launches"] > 0:
+                ia = iso_st["flop"] / (iso_st["sum_ms"] * 1e-3) / 1e12
+                r.update({"isolated_achieved": ia, "isolated_frac": ia / MFMA_F64_PEAK_TFLOPS,
+                          "isolated_avg_launch_us": 1e3 * iso_st["sum_ms"] / iso_st["launches"],
+                          "note": "achieved/frac: timed region, where a launch shares the CUs with the inverse blocks "
+                                  "on the other streams; isolated_*: same kernel, overlap off"})
+            return r
+
+        # the dominant kernel of the factorisation: the wide trailing update when the two-speed schedule is on
+        # (most of the flop), else the step kernel (all of it)
+        wide_dominant = kw["launches"] > 0 and kw["flop"] * 8 > ks.get("flop", 0.0)   # step launches are sampled 1 in 8
         if ks["launches"] > 0:
-            ach = ks["flop"] / (ks["sum_ms"] * 1e-3) / 1e12
-            out["roofline"] = {
-                "kernel": "k_syrk_step (Cholesky trailing update, fp64 MFMA 16x16x4, K=128 per launch)",
-                "bound": "mfma", "achieved": ach, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": ach / MFMA_F64_PEAK_TFLOPS, "traffic": traffic,
-                "launches": int(ks["launches"]), "avg_launch_us": 1e3 * ks["sum_ms"] / ks["launches"],
-                "algorithmic_flop_per_launch": ks["flop"] / ks["launches"],
-            }
-            if iso is not None:
-                out["roofline"]["note"] = ("achieved/frac: timed region, where a launch shares the CUs with the inverse "
-                                           "blocks on the other streams; isolated_*: same kernel, overlap off")
-            if iso and iso["launches"] > 0:
-                ia = iso["flop"] / (iso["sum_ms"] * 1e-3) / 1e12
-                out["roofline"].update({"isolated_achieved": ia, "isolated_frac": ia / MFMA_F64_PEAK_TFLOPS,
-                                        "isolated_avg_launch_us": 1e3 * iso["sum_ms"] / iso["launches"]})
+            step = roof("k_syrk_step", "k_syrk_step (Cholesky trailing update + next diagonal block, fp64 MFMA 16x16x4, "
+                        "K=128 per launch)", ks, iso)
+            if wide_dominant:
+                out["roofline"] = roof("k_syrk_wide", "k_syrk_wide (Cholesky far trailing update, fp64 MFMA 16x16x4, "
+                                       "K=128*panel per launch)", kw, iso_w if iso is not None else None)
+                out["roofline_step"] = step
+            else:
+                out["roofline"] = step
             out["roofline"]["whole_evaluation_frac"] = out["eval_tflops_n3"] / MFMA_F64_PEAK_TFLOPS
+        if timed_launches and ph["kbuild"] == ph["kbuild"]:
+            # SE-kernel build: lower 64x64 tiles of K written once (+ X read), HIP events around its launch
+            nbytes = (npad // 64) * (npad // 64 + 1) // 2 * 64 * 64 * 8 + args.n * args.d * 8
+            gbs = nbytes / (ph["kbuild"] * 1e-3) / 1e9
+            out["roofline_kbuild"] = {"kernel": "k_build (SE covariance, lower tiles)", "bound": "hbm", "achieved": gbs,
+                                      "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                                      "traffic": pmc.get("k_build", {}).get("hbm_bytes_per_launch"),
+                                      "traffic_source": PMC_SUMMARY if "k_build" in pmc else None,
+                                      "launch_us": 1e3 * ph["kbuild"], "algorithmic_bytes": nbytes,
+                                      "note": "bound in practice by N^2/2 fp64 exp evaluations, not by HBM"}
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, args.n), args.n, args.d)
         print(json.dumps(out), flush=True)

@@ -15,6 +15,8 @@ LIB_PATH = os.path.join(HERE, "lib", "libcugp.so")
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int)
 OBJECTIVE = C.CFUNCTYPE(None, C.c_void_p, _dp, _dp, _dp)
+VALUE_FN = C.CFUNCTYPE(None, C.c_void_p, _dp, _dp)
+GRADIENT_FN = C.CFUNCTYPE(None, C.c_void_p, _dp, _dp)
 
 CUGP_OK = 0
 ERR_NAMES = {-1: "CUGP_ERR_INVALID", -2: "CUGP_ERR_NOMEM", -3: "CUGP_ERR_DEVICE", -4: "CUGP_ERR_NODEVICE"}
@@ -66,6 +68,8 @@ SIGNATURES = {
     "cugp_cg_minimize": (C.c_int, [OBJECTIVE, C.c_void_p, _dp, C.c_int, _dp, C.c_int, _ip]),
     "cugp_rprop_minimize": (C.c_int, [OBJECTIVE, C.c_void_p, _dp, C.c_int, _dp, C.c_int, _ip]),
     "cugp_cg_solve": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, _ip]),
+    "cugp_cg_minimize_sparing": (C.c_int, [VALUE_FN, GRADIENT_FN, C.c_void_p, _dp, C.c_int, _dp, C.c_int, _ip, _ip]),
+    "cugp_cg_solve_sparing": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, _ip, _ip]),
     "cugp_rprop_solve": (C.c_int, [C.c_void_p, C.c_int, _dp, C.c_int, _ip]),
     "cugp_bcm_create": (C.c_int, [C.c_int, _ip, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "cugp_bcm_create_split": (C.c_int, [_dp, _dp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),

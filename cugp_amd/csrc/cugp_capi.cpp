@@ -78,6 +78,7 @@ struct cugp_gp {
     hipStream_t chain = nullptr;    // ... and the panel chain itself, on its OWN compute units (CU-masked streams: a
     hipStream_t widem = nullptr;    //     latency-bound chain kernel sharing a CU with MFMA tile products runs 3-5x slower)
     int chain_cus = -1;             // compute units the masked pair was created for
+    int inv_reserve = -1;           // compute units the inverse streams (aux, aux2, lq) were created to stay off
     hipEvent_t cfork = nullptr, cjoin = nullptr;   // main -> chain at the start of a factorisation, chain -> main at its end
     std::vector<hipEvent_t> bev;    // fork events, one per inverse block, + the join event (last)
     std::vector<hipEvent_t> oev;    // "block's own inverse done" events (aux2 -> aux)
@@ -309,6 +310,32 @@ int ensure_partition_streams(cugp_gp* g, int ncu)
     return CUGP_OK;
 }
 
+// The streams of the inverse blocks may be confined to all but `reserve` compute units (hipExtStreamCreateWithCUMask):
+// beside a saturated chip the factorisation's launches (panel solve, step kernel with the diagonal block inside)
+// waited 100-250 us per step for workgroup slots held by the inverse's long tiles; with a few CUs the inverse
+// never touches, the dispatcher always has room for them.  (Re)created when the tuning changes.
+int ensure_inverse_streams(cugp_gp* g)
+{
+    const int reserve = g_tune[TUNE_INVERSE_RESERVE];
+    if (g->inv_reserve == reserve) return CUGP_OK;
+    for (hipStream_t* sp : {&g->aux, &g->aux2, &g->lq}) {
+        if (*sp) { (void)hipStreamSynchronize(*sp); (void)hipStreamDestroy(*sp); *sp = nullptr; }
+    }
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, g->device));
+    const int total = prop.multiProcessorCount;
+    if (reserve <= 0 || reserve > total - 8) {
+        for (hipStream_t* sp : {&g->aux, &g->aux2, &g->lq}) HIPCHK(hipStreamCreateWithFlags(sp, hipStreamNonBlocking));
+    } else {
+        const int words = (total + 31) / 32;
+        std::vector<uint32_t> mk(words, 0u);
+        for (int i = reserve; i < total; i++) mk[i / 32] |= 1u << (i % 32);
+        for (hipStream_t* sp : {&g->aux, &g->aux2, &g->lq}) HIPCHK(hipExtStreamCreateWithCUMask(sp, (uint32_t)words, mk.data()));
+    }
+    g->inv_reserve = reserve;
+    return CUGP_OK;
+}
+
 // panel width of the look-ahead factorisation for this handle (1 = classic right-looking, K = 128 per pass)
 int panel_width(const cugp_gp* g)
 {
@@ -351,6 +378,8 @@ double trailing_flop(int nt, int ca, int cb, int kw)
 // one k_syrk_wide pass per panel over the far columns.  Every tile sees its updates in a fixed order whatever
 // the timing: results are reproducible.
 // with_inverse: L^-1 and K^-1 are built block row by block row on further streams as the rows of L become final.
+int enqueue_continue(cugp_gp* g);
+
 int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false)
 {
     int rc;
@@ -358,6 +387,7 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false)
     const int w = pipe_block(g, with_inverse);
     const int P = panel_width(g);
     const int near = g_tune[TUNE_NEAR_TILES];
+    if (w > 0 && (rc = ensure_inverse_streams(g))) return rc;
     // streams: classic form -- everything on the handle's stream; look-ahead form -- the chain and the wide
     // updates on disjoint sets of compute units (or, partition off, the chain on the handle's stream)
     hipStream_t m = g->stream, wq = g_tune[TUNE_WIDE_STREAM] != 0 ? g->wide : g->stream;
@@ -557,6 +587,35 @@ int enqueue_eval(cugp_gp* g, bool want_grad)
     return CUGP_OK;
 }
 
+// Gradient quantities from a factor that is already valid (a log-likelihood-only evaluation at the same data and
+// hyper-parameters came first: Covsum::compute_loglikelihood then compute_gradient_loghyperparam, or the value and
+// gradient halves of the evaluation-sparing line search): L^-1, K^-1, alpha, traces -- no rebuild of K, no second
+// factorisation.  One stream (the factorisation it could have run beside is over).
+int enqueue_continue(cugp_gp* g)
+{
+    int rc;
+    if ((rc = fetch_eval(g))) return rc;
+    if (!g->factor_valid) return fail(CUGP_ERR_INVALID, "no valid factor to continue from");
+    if ((rc = use_device(g))) return rc;
+    if ((rc = ensure_inverse_bufs(g))) return rc;
+    if (const int pe = prepare_kernels())
+        return fail(CUGP_ERR_DEVICE, "hipFuncSetAttribute(MaxDynamicSharedMemorySize)", (hipError_t)pe);
+    const HyperScalars h = scalars(g);
+    hipStream_t s = g->stream;
+    g->inverse_valid = false;
+    if ((rc = enqueue_inverse_block(g, 0, g->nt, true, s, nullptr, nullptr))) return rc;
+    launch_trmv_lower(g->dT, g->npad, g->npad, g->dy, g->dz, s);
+    launch_trmv_upper(g->dU, g->npad, g->npad, g->dz, g->dalpha, s);
+    launch_trace(g->dX, g->n, g->d, g->npad, h, g->dKinv, g->dalpha, g->dpart, s);
+    launch_finalize(g->dz, g->npad, g->n, g->dlogdet, g->nt, g->dpart, g->nblocks_trace, h, g->dout, s);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(g->hout, g->dout, 6 * sizeof(double), hipMemcpyDeviceToHost, s));
+    g->pending = true;
+    g->pending_grad = true;
+    g->pev_valid = false;
+    return CUGP_OK;
+}
+
 int fetch_eval(cugp_gp* g)
 {
     if (!g->pending) return CUGP_OK;
@@ -617,6 +676,7 @@ int cugp_create_padded(int n, int d, int device, int npad_min, cugp_gp** out)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->aux, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->aux2, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->lq, hipStreamNonBlocking);
+    g->inv_reserve = 0;             // (ensure_inverse_streams rebuilds them CU-masked when asked to)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->wide, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->cfork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&g->cjoin, hipEventDisableTiming);
@@ -783,7 +843,8 @@ int cugp_loglik_grad(cugp_gp* g, double* ll, double gr[3])
     int rc;
     if ((rc = fetch_eval(g))) return rc;
     if (!g->inverse_valid) {
-        if ((rc = enqueue_eval(g, true))) return rc;
+        // a valid factor (cugp_loglik came first at the same point) is continued, not recomputed
+        if ((rc = (g->factor_valid && g->prof == 0) ? enqueue_continue(g) : enqueue_eval(g, true))) return rc;
         if ((rc = fetch_eval(g))) return rc;
     }
     if (ll) *ll = g->last_ll;
@@ -1134,6 +1195,32 @@ int cugp_cg_solve(cugp_gp* g, int budget, double* trace, int trace_cap, int* nev
     int rc = cugp_cg_minimize(gp_objective, g, th, budget, trace, trace_cap, nevals);
     if (rc) return rc;
     return cugp_set_loghyper(g, th);       // covkernel.cpp:646
+}
+
+namespace {
+void gp_value(void* ctx, const double th[3], double* f)
+{
+    cugp_gp* g = (cugp_gp*)ctx;
+    double ll = NAN;
+    cugp_set_loghyper(g, th);
+    if (cugp_loglik(g, &ll) != CUGP_OK) ll = NAN;
+    *f = -1.0 * ll;
+}
+void gp_gradient(void* ctx, const double th[3], double gr[3])
+{
+    cugp_gp* g = (cugp_gp*)ctx;
+    cugp_set_loghyper(g, th);                   // unchanged point: the factor of the value call stays valid
+    if (cugp_grad(g, gr) != CUGP_OK) gr[0] = gr[1] = gr[2] = NAN;
+}
+}  // namespace
+
+int cugp_cg_solve_sparing(cugp_gp* g, int budget, double* trace, int trace_cap, int* nevals, int* ngrads)
+{
+    if (!g) return CUGP_ERR_INVALID;
+    double th[3] = {g->hp[0], g->hp[1], g->hp[2]};
+    int rc = cugp_cg_minimize_sparing(gp_value, gp_gradient, g, th, budget, trace, trace_cap, nevals, ngrads);
+    if (rc) return rc;
+    return cugp_set_loghyper(g, th);
 }
 
 int cugp_rprop_solve(cugp_gp* g, int iters, double* trace, int trace_cap, int* nevals)

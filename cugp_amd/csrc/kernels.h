@@ -24,7 +24,10 @@ enum { TUNE_LAUUM_WM2_MAX = 0,   // K^-1 product: use 64x64 tiles when there are
        TUNE_STEP_STREAM = 13,    // two-speed step kernel: non-temporal accesses to the C tiles (1) or plain ones (0)
        TUNE_CHAIN_CUS = 14,      // experimental two-stream form: compute units reserved for the panel chain (CU-masked streams); 0 = no partition
        TUNE_WIDE_STREAM = 15,    // wide updates on the handle's stream (0) or on their own stream beside the next panel's chain (1, experimental)
-       TUNE_COUNT = 16 };
+       TUNE_INVERSE_RESERVE = 16, // compute units the inverse-block streams stay off (CU-masked), so the factorisation's launches always find free slots; 0 = no mask
+       TUNE_SPLIT_REM_MAX = 17,  // uniform-K launches (block-wise K^-1 share, bordering, wide update): a last round of at most this many tiles runs as 64x64 quarters
+       TUNE_STEP_QUARTER_MAX = 18, // step kernel: launches of at most this many 64x64 workgroups run ALL their tiles as quarters (chain-bound tail)
+       TUNE_COUNT = 19 };
 extern int g_tune[TUNE_COUNT];
 
 struct HyperScalars;

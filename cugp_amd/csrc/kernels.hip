@@ -314,15 +314,12 @@ __device__ __forceinline__ void trap_index(int idx, int wcol, int& ti, int& tj)
 // inverse rows [a, a+w) at a time:  Kinv(ti,tj) (+)= sum_{k in [max(ti,a), a+w)} U[ti][k] U[tj][k]^T
 // for tj <= ti < a+w.  a = 0, w = nt is the whole product in one launch.
 template <int WM>
-__global__ __launch_bounds__(256, 2) void k_lauum(const double* __restrict__ U, double* __restrict__ Kinv, int ld,
-                                                  int a, int w, const ExpertPtrs* __restrict__ bt)
+__device__ __forceinline__ void lauum_tile(const double* __restrict__ U, double* __restrict__ Kinv, int ld, int a, int w,
+                                           int tile, int sub, char* smem)
 {
-    if (bt) { U = bt[blockIdx.y].U; Kinv = bt[blockIdx.y].Kinv; }
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SUB = 4 / WM, BT = 32 * WM;
     int ti, tj;
-    tri_index(blockIdx.x / (SUB * SUB), ti, tj);       // ascending ti = longest k ranges first
-    const int sub = blockIdx.x % (SUB * SUB);
+    tri_index(tile, ti, tj);                           // ascending ti = longest k ranges first
     const int si = (sub / SUB) * BT, sj = (sub % SUB) * BT;
     double* C = Kinv + (size_t)(ti * TILE + si) * ld + tj * TILE + sj;
     d4 acc[WM][WM];
@@ -331,6 +328,24 @@ __global__ __launch_bounds__(256, 2) void k_lauum(const double* __restrict__ U, 
     tile_nt<false>(U + (size_t)(ti * TILE + si) * ld, ld, U + (size_t)(tj * TILE + sj) * ld, ld,
                    (ti < a ? a : ti) * TILE, (a + w) * TILE, acc, smem);
     tile_store(C, ld, acc, 1.0);
+}
+
+// nfull (WM = 4 only): the first nfull tiles as 128x128 workgroups, the rest -- a last, partly empty round of 512
+// workgroup slots that would take a whole tile time -- as four 64x64 workgroups each (split_round below)
+template <int WM>
+__global__ __launch_bounds__(256, 2) void k_lauum(const double* __restrict__ U, double* __restrict__ Kinv, int ld,
+                                                  int a, int w, int nfull, const ExpertPtrs* __restrict__ bt)
+{
+    if (bt) { U = bt[blockIdx.y].U; Kinv = bt[blockIdx.y].Kinv; }
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (WM == 2) {
+        lauum_tile<2>(U, Kinv, ld, a, w, blockIdx.x >> 2, blockIdx.x & 3, smem);
+    } else if ((int)blockIdx.x < nfull) {
+        lauum_tile<4>(U, Kinv, ld, a, w, blockIdx.x, 0, smem);
+    } else {
+        const int y = blockIdx.x - nfull;
+        lauum_tile<2>(U, Kinv, ld, a, w, nfull + (y >> 2), y & 3, smem);
+    }
 }
 
 // ---- triangular inverse.  [A 0; C B]^-1 = [TA 0; -TB C TA, TB] with A = tiles [.., b0), B = tiles [b0, ..):
@@ -397,20 +412,33 @@ __global__ __launch_bounds__(256, 2) void k_trtri_level(const double* __restrict
 // onto the last; the host issues chunk [c0, c1) for ALL rows below it as soon as those inverse rows are
 // final (uniform K, and most of the work is done before the rows' own turn comes).
 template <int WM>
-__global__ __launch_bounds__(256, 2) void k_trtri_border(const double* __restrict__ L, double* __restrict__ T,
-                                                         double* __restrict__ U, int ld, int a, int w, int step,
-                                                         int c0, int c1, const ExpertPtrs* __restrict__ bt)
+__device__ __forceinline__ void border_tile(const double* __restrict__ L, double* __restrict__ T, double* __restrict__ U,
+                                            int ld, int a, int w, int step, int c0, int c1, int blk, int sub, char* smem)
 {
-    if (bt) { L = bt[blockIdx.y].A; T = bt[blockIdx.y].T; U = bt[blockIdx.y].U; }
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int SUB = 4 / WM;
-    const int blk = blockIdx.x / (SUB * SUB), sub = blockIdx.x % (SUB * SUB);
     if (step == 1) {
         const int tj = blk / w, ti = a + blk % w;                       // tj < c1
         trtri_tile<WM>(L, T, U, ld, tj, ti, 1, tj > c0 ? tj : c0, c1, tj < c0, sub, smem);
     } else {
         const int tj = blk % a, ti = a + w - 1 - blk / a;               // longest k range first
         trtri_tile<WM>(L, T, U, ld, tj, ti, 2, a, ti + 1, false, sub, smem);
+    }
+}
+
+// nfull (WM = 4 only): tiles beyond it run as four 64x64 workgroups each (the last, partly empty round; split_round)
+template <int WM>
+__global__ __launch_bounds__(256, 2) void k_trtri_border(const double* __restrict__ L, double* __restrict__ T,
+                                                         double* __restrict__ U, int ld, int a, int w, int step,
+                                                         int c0, int c1, int nfull, const ExpertPtrs* __restrict__ bt)
+{
+    if (bt) { L = bt[blockIdx.y].A; T = bt[blockIdx.y].T; U = bt[blockIdx.y].U; }
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (WM == 2) {
+        border_tile<2>(L, T, U, ld, a, w, step, c0, c1, blockIdx.x >> 2, blockIdx.x & 3, smem);
+    } else if ((int)blockIdx.x < nfull) {
+        border_tile<4>(L, T, U, ld, a, w, step, c0, c1, blockIdx.x, 0, smem);
+    } else {
+        const int y = blockIdx.x - nfull;
+        border_tile<2>(L, T, U, ld, a, w, step, c0, c1, nfull + (y >> 2), y & 3, smem);
     }
 }
 
@@ -674,32 +702,74 @@ __device__ __forceinline__ double rsqrt_nr(double x)
     return y;
 }
 
-// Cholesky of one 16x16 micro tile held in LDS (rows padded to 17), by ONE wave: lane l owns row
-// l & 15 in registers, right-looking.  A wave issues one fp64 VALU instruction per ~6.5 cycles, so the
-// pivot loop (the latency floor of the whole factorisation) is written for few instructions and no stalls:
+// Cholesky of one 16x16 micro tile held in LDS (rows padded to 17) together with everything that hangs on it, by
+// up to three waves side by side.  Lane l < 16 of every wave owns row l of the diagonal tile in registers (each wave
+// factors the tile for itself: no hand-over between waves inside the pivot loop), right-looking.  A wave issues
+// one fp64 VALU instruction per ~6.5 cycles, so the pivot loop (the latency floor of the whole factorisation) is
+// written for few instructions and no stalls:
 //   * 1/sqrt(pivot): v_rsq_f64 seed (2^-24) + ONE third-order step y0 (1 + e/2 + 3e^2/8), e = 1 - x y0^2,
 //     folded into the column scaling (error 5/16 e^3 ~ 3e-24: below rounding);
 //   * column c+1 is updated at once with a v_readlane broadcast and gives the next pivot, so the next
 //     1/sqrt chain starts immediately;
 //   * the factors for columns >= c+2 go through a 128-byte LDS buffer and come back as uniform 16-byte
 //     reads; they are applied ONE PIVOT LATER, so the LDS round trip never stalls the chain.
-// Writes the factor back (upper zeroed) and 1/L_cc into rinv[0..15].  colbuf: 32 doubles of LDS.
-__device__ __forceinline__ void micro_factor(double* __restrict__ tile, double* __restrict__ rinv,
+// Every instruction of that loop runs on all 64 lanes, so lanes 16..63 carry OTHER ROWS through the same
+// elimination for free:
+//   * rows of the column block below the diagonal tile (48 per wave): they come out as x = a L_jj^-T, the forward
+//     substitution that used to be a separate pass of ~3.3k cycles per 16-step;
+//   * one group of 16 lanes (in the first wave with room) starts from the rows of the IDENTITY: row i comes out as
+//     column i of L_jj^-1 -- the 16x16 inverse the 64x64 inverses are built from, which used to cost a
+//     ~5k-cycle substitution per tile.
+// Two calls with a workgroup barrier between them: panel_load (everybody reads the diagonal tile) and
+// panel_factor (the owner's rows go straight to global memory, the inverse replaces the diagonal tile in LDS).
+// workgroup barrier that orders LDS traffic only: global stores in flight are NOT waited for (a __syncthreads
+// would be: ~2k cycles at every barrier once the factored diagonal tiles go straight to global memory)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct PanelLanes {
+    double* myrow;      // LDS row this lane loads from / stores to (rows below), or the diagonal-tile row (lanes < 16)
+    int kind;           // 0 diagonal-tile row, 1 row of the column block below, 2 identity row, 3 idle
+    int idx;            // identity rows: which unit vector
+};
+
+// IDENT: lanes [inv_lane0, inv_lane0 + 16) carry the identity rows.  (The selects and the extra stores cost
+// ~1.6k cycles per call, more than the inverse is worth on the critical path while other waves have time for the
+// substitution form (micro_inverse): used for the LAST diagonal tile only, whose inverse nothing else could hide.)
+template <bool IDENT>
+__device__ __forceinline__ void panel_load(double* __restrict__ sm, int jb, int nrows, int q0, int inv_lane0,
+                                           PanelLanes& pl, double (&r)[MT])
+{
+    const int lane = threadIdx.x & 63;
+    const int q = q0 + lane - MT;                              // my row of the column block (lanes >= 16)
+    pl.kind = lane < MT ? 0 : (q < nrows ? 1 : ((IDENT && lane >= inv_lane0 && lane < inv_lane0 + MT) ? 2 : 3));
+    pl.idx = lane - inv_lane0;
+    // (idle and identity lanes read a row of the diagonal tile: every lane loads unconditionally)
+    pl.myrow = pl.kind == 1 ? sm + mt_off(jb + 1 + (q >> 4), jb) + (q & 15) * (MT + 1)
+                            : sm + mt_off(jb, jb) + (lane & 15) * (MT + 1);
+#pragma unroll
+    for (int c = 0; c < MT; c++) {
+        const double v = pl.myrow[c];
+        r[c] = (IDENT && pl.kind == 2) ? (c == pl.idx ? 1.0 : 0.0) : v;
+    }
+}
+
+// gdiag (owner wave only, else null): where row 0 of the diagonal tile lives in global memory (row stride ld)
+template <bool IDENT>
+__device__ __forceinline__ void panel_factor(double* __restrict__ sm, int jb, const PanelLanes& pl, double (&r)[MT],
+                                             double* __restrict__ gdiag, int ld, double* __restrict__ rinv,
                                              double* __restrict__ colbuf)
 {
-    const int lane = threadIdx.x & 63, i = lane & 15;
-    double r[MT];
-#pragma unroll
-    for (int c = 0; c < MT; c++) r[c] = tile[i * (MT + 1) + c];
+    const int lane = threadIdx.x & 63;
+    const bool diag = lane < MT;
     double piv = readlane_f64(r[0], 0);
     double myrinv = 0.0;
     double lprev = 0.0;                       // my factor of the previous pivot column
-    d2 oprev[MT / 2];                         // the previous pivot column, as read back from LDS
+    d2 oprev[MT / 2];                         // the previous pivot column (rows of the diagonal tile), read back from LDS
 #pragma unroll
     for (int c = 0; c < MT; c++) {
         const double y0 = __builtin_amdgcn_rsq(piv);
         const double e = __builtin_fma(-piv * y0, y0, 1.0);
-        const double q = e * __builtin_fma(e, 0.375, 0.5);
+        const double qq = e * __builtin_fma(e, 0.375, 0.5);
         // deferred: previous pivot's column applied to columns >= c+1 (column c got it right away)
         if (c >= 1) {
 #pragma unroll
@@ -709,45 +779,67 @@ __device__ __forceinline__ void micro_factor(double* __restrict__ tile, double* 
             }
         }
         const double ry = r[c] * y0;
-        const double lc = __builtin_fma(ry, q, ry);
+        const double lc = __builtin_fma(ry, qq, ry);
         r[c] = lc;
-        myrinv = (i == c) ? __builtin_fma(y0, q, y0) : myrinv;
+        myrinv = (lane == c) ? __builtin_fma(y0, qq, y0) : myrinv;
         if (c + 1 < MT) {
-            const double o1 = readlane_f64(lc, c + 1);
+            const double o1 = readlane_f64(lc, c + 1);                 // L[c+1][c] of the diagonal tile
             r[c + 1] = __builtin_fma(-lc, o1, r[c + 1]);              // column c+1, every row
             piv = readlane_f64(r[c + 1], c + 1);                      // next pivot
             if (c + 2 < MT) {
                 double* cb = colbuf + (c & 1) * MT;
-                cb[i] = lc;                                           // lanes 16..63 mirror the same values
+                if (diag) cb[lane] = lc;                              // column c of the diagonal tile
+                // lanes 16..63 read what lanes 0..15 just wrote: tell the compiler (to which a lane that stored
+                // nothing may keep the values it read from this buffer two pivots ago) that LDS has changed;
+                // the hardware executes a wave's LDS operations in order, so no instruction is needed
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
                 for (int c2 = (c + 2) & ~1; c2 < MT; c2 += 2) oprev[c2 / 2] = *(const d2*)(cb + c2);
                 lprev = lc;
             }
         }
     }
-    if (lane < MT) {
-        rinv[i] = myrinv;
+    if (pl.kind == 0) {
+        if (gdiag) {                                                  // the factor's diagonal tile: final, to global
+            rinv[lane] = myrinv;
+            double* g = gdiag + (size_t)lane * ld;
 #pragma unroll
-        for (int c = 0; c < MT; c++) tile[i * (MT + 1) + c] = (c <= i) ? r[c] : 0.0;
+            for (int c = 0; c < MT; c += 2) *(d2*)(g + c) = (d2){c <= lane ? r[c] : 0.0, c + 1 <= lane ? r[c + 1] : 0.0};
+            if (!IDENT) {                                             // ... and to LDS for micro_inverse_inplace
+#pragma unroll
+                for (int c = 0; c < MT; c++) pl.myrow[c] = r[c];      // (entries above the diagonal are never read)
+            }
+        }
+    } else if (pl.kind == 1) {
+#pragma unroll
+        for (int c = 0; c < MT; c++) pl.myrow[c] = r[c];
+    } else if (IDENT && pl.kind == 2) {
+        // my row is column idx of L_jj^-1: the inverse replaces the diagonal tile in LDS (nobody reads L_jj there
+        // any more: the other waves took their copy before the barrier, the factor itself went to global memory)
+        double* tile = sm + mt_off(jb, jb);
+#pragma unroll
+        for (int c = 0; c < MT; c++) tile[c * (MT + 1) + pl.idx] = r[c];
     }
 }
 
-// inverse of one factored 16x16 micro tile: lane j builds column j of L^-1 by forward substitution
-__device__ __forceinline__ void micro_inverse(const double* __restrict__ Ljj, const double* __restrict__ rinv,
-                                              double* __restrict__ dst)
+// inverse of one factored 16x16 micro tile IN PLACE in LDS: lane j builds column j of L^-1 by forward substitution,
+// column by column of L (right-looking: the dependent chain is t_k -> t_(k+1), the 120 updates in between are
+// independent).  The factor itself is already in global memory (panel_factor), nobody reads it from LDS any more.
+__device__ __forceinline__ void micro_inverse_inplace(double* __restrict__ tile, const double* __restrict__ rinv)
 {
     const int lane = threadIdx.x & 63, j = lane & 15;
     double tc[MT];
 #pragma unroll
-    for (int i = 0; i < MT; i++) {
-        double sacc = (i == j) ? 1.0 : 0.0;
+    for (int i = 0; i < MT; i++) tc[i] = (i == j) ? 1.0 : 0.0;
 #pragma unroll
-        for (int k = 0; k < i; k++) sacc = __builtin_fma(-Ljj[i * (MT + 1) + k], tc[k], sacc);
-        tc[i] = sacc * rinv[i];
+    for (int k = 0; k < MT; k++) {
+        tc[k] *= rinv[k];
+#pragma unroll
+        for (int i = k + 1; i < MT; i++) tc[i] = __builtin_fma(-tile[i * (MT + 1) + k], tc[k], tc[i]);
     }
     if (lane < MT) {
 #pragma unroll
-        for (int i = 0; i < MT; i++) dst[i * MT + j] = tc[i];
+        for (int i = 0; i < MT; i++) tile[i * (MT + 1) + j] = tc[i];
     }
 }
 
@@ -770,6 +862,72 @@ __device__ __forceinline__ void micro_update(double* __restrict__ sm, int bi, in
     }
 #pragma unroll
     for (int r = 0; r < 4; r++) C[(g + 4 * r) * (MT + 1) + c] = acc[r] + acc2[r];
+}
+
+// The same for NB tiles at once (tile n of the step = the n-th of (bj = jb+1.., bi = bj..7) in that order): all
+// operands of the batch are requested before the first MFMA and the NB x 4 MFMAs are independent, so the LDS
+// latency and the MFMA latency of one tile hide behind the others (one tile at a time took ~1100 cycles, 4 MFMAs
+// of 64).  Tiles past the end of the step (n >= ntiles) are skipped wave-uniformly.
+template <int NB>
+__device__ __forceinline__ void micro_update_batch(double* __restrict__ sm, int jb, int n0, int stride, int nend)
+{
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const int mm = NMT - 1 - jb;                       // tiles per edge of the trailing part
+    double* C[NB];
+    const double *Xi[NB], *Xj[NB];
+    bool on[NB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        const int n = __builtin_amdgcn_readfirstlane(n0 + b * stride);
+        on[b] = n < nend;
+        // n -> (column cj, row ri) of the trailing lower triangle, column by column: column cj holds mm - cj tiles
+        int cj = 0, rem = on[b] ? n : 0;
+        while (rem >= mm - cj) { rem -= mm - cj; cj++; }
+        const int bj = jb + 1 + cj, bi = bj + rem;
+        C[b] = sm + mt_off(bi, bj);
+        Xi[b] = sm + mt_off(bi, jb);
+        Xj[b] = sm + mt_off(bj, jb);
+    }
+    d4 acc[NB], acc2[NB];
+    double xa[NB][4], xb[NB][4];
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[b][r] = C[b][(g + 4 * r) * (MT + 1) + c];
+#pragma unroll
+        for (int s = 0; s < 4; s++) {
+            xa[b][s] = -Xi[b][c * (MT + 1) + 4 * s + g];
+            xb[b][s] = Xj[b][c * (MT + 1) + 4 * s + g];
+        }
+        acc2[b] = (d4){0.0, 0.0, 0.0, 0.0};
+    }
+    // every operand of the batch is on its way before the first MFMA waits for one (left alone the scheduler
+    // interleaves loads and MFMAs tile by tile with a full LDS wait in front of each)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 4; s += 2)
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[b][s], xb[b][s], acc[b], 0, 0, 0);
+            acc2[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[b][s + 1], xb[b][s + 1], acc2[b], 0, 0, 0);
+        }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+        if (on[b]) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) C[b][(g + 4 * r) * (MT + 1) + c] = acc[b][r] + acc2[b][r];
+        }
+}
+
+// tiles n = n0, n0 + stride, ... < nend of step jb's rank-16 update by the calling wave, four at a time
+__device__ __forceinline__ void micro_update_run(double* __restrict__ sm, int jb, int n0, int stride, int nend)
+{
+    for (int n = n0; n < nend; n += 4 * stride) {
+        if (n + 2 * stride < nend) micro_update_batch<4>(sm, jb, n, stride, nend);
+        else if (n + stride < nend) micro_update_batch<2>(sm, jb, n, stride, nend);
+        else micro_update_batch<1>(sm, jb, n, stride, nend);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -795,19 +953,6 @@ __device__ unsigned long long g_stamps[64];
 #else
 #define STAMP(i)
 #endif
-
-// inverse of diagonal micro tile q into d16 and its log-det share sum_i log L_ii = -sum_i log(1/L_ii)
-// into red[q] (one wave; lanes 16..63 contribute zero; fixed shuffle order -> reproducible)
-__device__ __forceinline__ void micro_inverse_logdet(const double* __restrict__ sm, const double* __restrict__ rinv,
-                                                     double* __restrict__ d16blk, double* __restrict__ red, int q)
-{
-    const int lane = threadIdx.x & 63;
-    micro_inverse(sm + mt_off(q, q), rinv + q * MT, d16blk + (size_t)q * (MT * MT));
-    double v = (lane < MT) ? -log(rinv[q * MT + lane]) : 0.0;
-#pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    if (lane == 0) red[q] = v;
-}
 
 // one MFMA 16x16x16 product on LDS micro tiles, "NN": acc += A(tile a)[row][k] * B(tile b)[k][col]
 __device__ __forceinline__ d4 micro_mma_nn(const double* __restrict__ a, const double* __restrict__ b, d4 acc)
@@ -843,8 +988,11 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ Ab, int ld, doub
                                            double* __restrict__ sm, double* __restrict__ red)
 {
     double* rinv = sm + NLT * MTS;                          // 1 / L_ii, 128 entries
-    double* colbuf = red + 64;                              // red[0..7]: log-det shares; red[64..95]: pivot columns
-    const int t = threadIdx.x, wave = t >> 6;
+    double* colbuf = red;                                   // pivot columns: 2 x 16 doubles for each of 3 waves
+    (void)d16blk;                                           // (16x16 inverses now live in LDS only)
+    // (the wave index through readfirstlane: the compiler then knows that everything decided by it -- which tiles
+    //  a wave updates, which rows it factors -- is wave-uniform and keeps that control flow on the scalar unit)
+    const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     __builtin_amdgcn_s_setprio(3);                          // this workgroup is the critical path of the step
 
     STAMP(0);
@@ -856,81 +1004,83 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ Ab, int ld, doub
     }
     __syncthreads();
     STAMP(1);
-    if (wave == 0) micro_factor(sm + mt_off(0, 0), rinv, colbuf);
-    __syncthreads();
+    // Step jb = (P) panel factor of micro-tile column jb: diagonal tile, the rows below it (48 per wave) and the
+    // identity rows that become its 16x16 inverse (panel_load / panel_factor); (U) rank-16 update of the trailing
+    // micro tiles.  Look-ahead: the update first brings column jb+1 up to date (U1, all waves), then the waves
+    // that hold rows of column jb+1 factor it (P of the next step) while the others finish the update (U2).
+    // rows below diagonal tile s: 16 * (7 - s).  Waves 0 .. rows/48 run P: wave rows/48 holds the last rows%48 rows
+    // and, behind them, the identity rows.
+    // (barriers in this loop order LDS traffic only -- lds_barrier: the diagonal tiles' global stores drain behind them)
+    PanelLanes pl;
+    double pr[MT];
+    double* gblk = Ab;                                       // global home of the 128x128 block (row stride ld)
+    {
+        const int rows = (NMT - 1) * MT, wlast = rows / 48;
+        if (wave <= wlast) panel_load<false>(sm, 0, rows, wave * 48, -1, pl, pr);
+        lds_barrier();
+        if (wave <= wlast) panel_factor<false>(sm, 0, pl, pr, wave == 0 ? gblk : nullptr, ld, rinv, colbuf + wave * 2 * MT);
+    }
+    lds_barrier();
     STAMP(2);
-
     for (int jb = 0; jb < NMT - 1; jb++) {
-        const int m = NMT - 1 - jb;                         // micro tiles below the diagonal one
-        // (B) rows below: x_c = (a_c - sum_{k<c} x_k L_ck) / L_cc
-        if (t < m * MT) {
-            const int bi = jb + 1 + (t >> 4), r = t & 15;
-            double* row = sm + mt_off(bi, jb) + r * (MT + 1);
-            const double* Ljj = sm + mt_off(jb, jb);
-            double x[MT];
-#pragma unroll
-            for (int c = 0; c < MT; c++) {
-                double sacc = row[c];
-#pragma unroll
-                for (int k = 0; k < c; k++) sacc = __builtin_fma(-x[k], Ljj[c * (MT + 1) + k], sacc);
-                x[c] = sacc * rinv[jb * MT + c];
-            }
-#pragma unroll
-            for (int c = 0; c < MT; c++) row[c] = x[c];
-        }
-        __syncthreads();
+        const int m = NMT - 1 - jb;                         // micro tiles per edge of the trailing part
+        const int ntiles = m * (m + 1) / 2;
+        micro_update_run(sm, jb, wave, 4, m);               // U1: column jb+1 = tiles 0 .. m-1
+        lds_barrier();
         STAMP(3 + 3 * jb);
-        // (C) trailing micro tiles of this 128 block
-        if (wave == 0) {
-            micro_update(sm, jb + 1, jb + 1, jb);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            STAMP(4 + 3 * jb);
-            micro_factor(sm + mt_off(jb + 1, jb + 1), rinv + (jb + 1) * MT, colbuf);
-            STAMP(5 + 3 * jb);
-        } else {
-            int n = 0;                                      // column jb+1 first, then the rest
-            for (int bi = jb + 2; bi < NMT; bi++, n++)
-                if (n % 3 == wave - 1) micro_update(sm, bi, jb + 1, jb);
-            for (int bj = jb + 2; bj < NMT; bj++)
-                for (int bi = bj; bi < NMT; bi++, n++)
-                    if (n % 3 == wave - 1) micro_update(sm, bi, bj, jb);
-            // inverses of finished diagonal micro tiles (+ their log-det share), only from step 3 on, when
-            // waves 1..3 have slack: tiles 0,1,2 at jb = 3; 3,4 at jb = 4; then one per step
-            int q = -1;
-            if (jb == 3) q = wave - 1;
-            else if (jb == 4) q = (wave <= 2) ? 2 + wave : -1;
-            else if (jb > 4 && wave == 1 + (jb % 3)) q = jb;
-            if (q >= 0) micro_inverse_logdet(sm, rinv, d16blk, red, q);
+        const int s1 = jb + 1, rows = (m - 1) * MT, np = rows > 48 ? 2 : 1;
+        // U2 = tiles m .. ntiles-1.  The first steps have more of them (21, 15) than two waves finish while the
+        // other two factor: the factoring waves take the last `ap` tiles each when they are done
+        const int ap = jb == 0 ? 2 : (jb == 1 ? 1 : 0);
+        const int nfree = ntiles - np * ap;
+        const bool last = s1 == NMT - 1;                    // no rows below: lanes 16..31 of wave 0 take the identity
+        if (wave < np) {
+            if (last) panel_load<true>(sm, s1, rows, wave * 48, MT, pl, pr);
+            else panel_load<false>(sm, s1, rows, wave * 48, -1, pl, pr);
         }
-        __syncthreads();
+        lds_barrier();                                      // every factoring wave has its copy of the diagonal tile
+        if (wave < np) {
+            double* gd = wave == 0 ? gblk + (size_t)s1 * MT * ld + s1 * MT : nullptr;
+            if (last) panel_factor<true>(sm, s1, pl, pr, gd, ld, rinv + s1 * MT, colbuf + wave * 2 * MT);
+            else panel_factor<false>(sm, s1, pl, pr, gd, ld, rinv + s1 * MT, colbuf + wave * 2 * MT);
+            if (ap > 0) micro_update_run(sm, jb, nfree + wave, np, ntiles);
+        } else {
+            micro_update_run(sm, jb, m + (wave - np), 4 - np, nfree);       // U2: the other columns
+            // 16x16 inverses of finished diagonal tiles (in place in LDS) while the last, small panels are
+            // factored: tiles 0, 1, 2 at s1 = 4; 3, 4 at s1 = 5; 5 at s1 = 6; 6 at s1 = 7 (7: identity lanes above)
+            int qi = -1;
+            if (s1 == 4) qi = wave - 1;
+            else if (s1 == 5) qi = wave <= 2 ? 2 + wave : -1;
+            else if (s1 >= 6 && wave == 1) qi = s1 - 1;
+            if (qi >= 0) micro_inverse_inplace(sm + mt_off(qi, qi), rinv + qi * MT);
+        }
+        lds_barrier();
+        STAMP(4 + 3 * jb);
     }
 
     STAMP(30);
-    if (wave == 1) micro_inverse_logdet(sm, rinv, d16blk, red, NMT - 1);
-    {   // factor back to global (lower micro tiles; diagonal tiles carry zeros above the diagonal)
+    {   // the rest of the factor back to global (the diagonal micro tiles went there as they were factored; their
+        // LDS copies now hold the 16x16 inverses)
         const int r = t >> 4, c = t & 15;
-        for (int bi = 0; bi < NMT; bi++)
-            for (int bj = 0; bj <= bi; bj++)
+        for (int bi = 1; bi < NMT; bi++)
+            for (int bj = 0; bj < bi; bj++)
                 Ab[(size_t)(bi * MT + r) * ld + bj * MT + c] = sm[mt_off(bi, bj) + r * (MT + 1) + c];
     }
+    // LDS has been read (the stores themselves stay in flight: a __syncthreads here would wait ~4k cycles for them)
+    lds_barrier();
     STAMP(31);
-    __syncthreads();
-    // log-determinant share of this block: the 8 micro-tile shares summed in a fixed order
-    if (t == 0) {
-        double acc = 0.0;
-        for (int jb = 0; jb < NMT; jb++) acc += red[jb];
-        *logdet_out = acc;
+    // log-determinant share of this block: sum_i log L_ii = -sum_i log(1/L_ii), 128 terms by one wave in a fixed order
+    if (wave == 3) {
+        const int lane = t & 63;
+        double v = -(log(rinv[lane]) + log(rinv[lane + 64]));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if (lane == 0) *logdet_out = v;
     }
     STAMP(32);
-
-    // ---- inverses of the two 64x64 diagonal sub-blocks, in place over the factor (already stored) ----
+    // ---- inverses of the two 64x64 diagonal sub-blocks from the 16x16 ones, in place (the sub-diagonal tiles they
+    // overwrite are on their way to global memory: the doubling below reads them first, barriers in between) ----
     // used by the panel solve: 3 short MFMA phases per strip instead of a 144-long dependent chain.
-    {   // 16x16 inverses (written to d16 above by this workgroup; the barriers above order them) -> diagonal tiles
-        const int r = t >> 4, c = t & 15;
-#pragma unroll
-        for (int jb = 0; jb < NMT; jb++) sm[mt_off(jb, jb) + r * (MT + 1) + c] = d16blk[jb * (MT * MT) + t];
-    }
-    __syncthreads();
     const d4 zero4 = (d4){0.0, 0.0, 0.0, 0.0};
     {   // 16 -> 32: pair p = wave: T21 = -T_B (L21 T_A)
         const int a = 2 * wave, b = 2 * wave + 1;
@@ -1408,7 +1558,7 @@ __global__ __launch_bounds__(256) void k_predict_finish(const double* __restrict
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-int g_tune[TUNE_COUNT] = {768, 1200, 384, -1, 511, 1, 1, 1 << 20, 4, 700, 1 << 20, 32, 1, 1, 0, 0};   // defaults chosen by interleaved A/B runs (tools/ab.py)
+int g_tune[TUNE_COUNT] = {768, 1200, 384, -1, 511, 1, 1, 1 << 20, 1, 700, 1 << 20, 32, 1, 1, 0, 0, 0, 256, 1536};   // defaults chosen by interleaved A/B runs (tools/ab.py)
 
 static inline int tri_count(int n) { return n * (n + 1) / 2; }
 
@@ -1497,6 +1647,10 @@ void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* d6
     const int ntl = trap_count(m, wcol) - 1;
     int nfull = ntl;
     if (ntl >= 512 && (ntl % 512) <= g_tune[TUNE_SYRK_REM_MAX]) nfull = ntl - ntl % 512;
+    // Few tiles (the chain-bound tail of the factorisation): a 128x128 workgroup alone on its CU issues one MFMA
+    // per ~138 cycles (one wave per SIMD: half the pipe's rate) and takes ~40 us -- as long as the diagonal block
+    // inside this launch.  As 64x64 quarters the same tiles take ~12 us per round of 512 workgroups.
+    if ((long long)ntl * bt.count * 4 <= g_tune[TUNE_STEP_QUARTER_MAX]) nfull = 0;
     const unsigned nwg = NDIAGWG + nfull + 4 * (ntl - nfull);
     hipLaunchKernelGGL(k_syrk_step, bt.tab ? dim3(bt.count, nwg) : dim3(nwg), dim3(256), STEP_LDS, s, A, ld, kb, d16,
                        d64, logdet_part, tickets, nfull, wcol, la0, kfirst, stream_c, bt.tab);
@@ -1540,18 +1694,31 @@ void launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, i
 
 // step 1 of the bordering, spread over time: add the k tiles [c0, c1) (a block of inverse rows that just
 // became final) to Wt(tj < c1, ti in [ra, ra+rw)) for ALL rows below the block
+// A launch of `tiles` uniform-ish 128x128 tiles fills the 512 workgroup slots round by round; a last round that is
+// mostly empty still costs a whole tile time (134 us at K = 512).  When the remainder is small its tiles run as
+// four 64x64 workgroups each instead: -> number of tiles launched whole (the rest are split).
+static int split_round(int tiles, int count)
+{
+    const int slots = 512 / (count > 0 ? count : 1) > 0 ? 512 / (count > 0 ? count : 1) : 1;
+    const int rem = tiles % slots;
+    if (tiles < slots || rem == 0 || rem > g_tune[TUNE_SPLIT_REM_MAX]) return tiles;
+    return tiles - rem;
+}
+
 void launch_trtri_border1(const double* L, double* T, double* U, int ld, int ra, int rw, int c0, int c1,
                           hipStream_t st, Batch bt)
 {
     const int tiles = c1 * rw;
     if (tiles <= 0) return;
     set_big_lds();
-    if (tiles * bt.count <= g_tune[TUNE_BORDER_WM2_MAX])
+    if (tiles * bt.count <= g_tune[TUNE_BORDER_WM2_MAX]) {
         hipLaunchKernelGGL(k_trtri_border<2>, dim3(tiles * 4, bt.count), dim3(256), Geo<2>::LDS, st, L, T, U, ld, ra, rw,
-                           1, c0, c1, bt.tab);
-    else
-        hipLaunchKernelGGL(k_trtri_border<4>, dim3(tiles, bt.count), dim3(256), GEMM_LDS, st, L, T, U, ld, ra, rw, 1, c0,
-                           c1, bt.tab);
+                           1, c0, c1, 0, bt.tab);
+    } else {
+        const int nfull = split_round(tiles, bt.count);
+        hipLaunchKernelGGL(k_trtri_border<4>, dim3(nfull + 4 * (tiles - nfull), bt.count), dim3(256), GEMM_LDS, st, L, T,
+                           U, ld, ra, rw, 1, c0, c1, nfull, bt.tab);
+    }
 }
 
 // step 2: rows [a, a+w) of the inverse from their finished Wt and the block's own inverse
@@ -1560,22 +1727,29 @@ void launch_trtri_border2(const double* L, double* T, double* U, int ld, int a, 
     const int tiles = a * w;
     if (tiles <= 0) return;
     set_big_lds();
-    if (tiles * bt.count <= g_tune[TUNE_TRTRI_WM2_MAX])
+    if (tiles * bt.count <= g_tune[TUNE_TRTRI_WM2_MAX]) {
         hipLaunchKernelGGL(k_trtri_border<2>, dim3(tiles * 4, bt.count), dim3(256), Geo<2>::LDS, st, L, T, U, ld, a, w, 2,
-                           0, 0, bt.tab);
-    else
-        hipLaunchKernelGGL(k_trtri_border<4>, dim3(tiles, bt.count), dim3(256), GEMM_LDS, st, L, T, U, ld, a, w, 2, 0, 0,
-                           bt.tab);
+                           0, 0, 0, bt.tab);
+    } else {
+        const int nfull = split_round(tiles, bt.count);
+        hipLaunchKernelGGL(k_trtri_border<4>, dim3(nfull + 4 * (tiles - nfull), bt.count), dim3(256), GEMM_LDS, st, L, T,
+                           U, ld, a, w, 2, 0, 0, nfull, bt.tab);
+    }
 }
 
 void launch_lauum(const double* U, double* Kinv, int ld, int a, int w, hipStream_t s, Batch bt)
 {
     set_big_lds();
     const int tiles = tri_count(a + w);
-    if (tiles * bt.count <= g_tune[TUNE_LAUUM_WM2_MAX])
-        hipLaunchKernelGGL(k_lauum<2>, dim3(tiles * 4, bt.count), dim3(256), Geo<2>::LDS, s, U, Kinv, ld, a, w, bt.tab);
-    else
-        hipLaunchKernelGGL(k_lauum<4>, dim3(tiles, bt.count), dim3(256), GEMM_LDS, s, U, Kinv, ld, a, w, bt.tab);
+    if (tiles * bt.count <= g_tune[TUNE_LAUUM_WM2_MAX]) {
+        hipLaunchKernelGGL(k_lauum<2>, dim3(tiles * 4, bt.count), dim3(256), Geo<2>::LDS, s, U, Kinv, ld, a, w, 0, bt.tab);
+    } else {
+        // (a whole-matrix product, a = 0, has k ranges from 1 to a+w tiles, longest first: its tail is short tiles
+        //  already; the split is for the block-wise calls, whose tiles all take w k tiles)
+        const int nfull = a > 0 ? split_round(tiles, bt.count) : tiles;
+        hipLaunchKernelGGL(k_lauum<4>, dim3(nfull + 4 * (tiles - nfull), bt.count), dim3(256), GEMM_LDS, s, U, Kinv, ld,
+                           a, w, nfull, bt.tab);
+    }
 }
 
 void launch_predict_gemm(const double* Ks, const double* T, double* W, int ld, int ntt, int nt, hipStream_t s)

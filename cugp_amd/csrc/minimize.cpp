@@ -8,6 +8,15 @@
 // grad taken at every probe, NaN/Inf probes answered by bisecting the step.
 // cugp_rprop_minimize follows covkernel.cpp:337-402.
 //
+// cugp_cg_minimize_sparing is the same loop with an objective split in two (value, then gradient at the same
+// point): the gradient -- two thirds of an evaluation on the GPU -- is only asked for where the line search
+// can use it.  A probe with f > f0 (the value the search started from) fails the sufficient-decrease test
+// whatever its slope, is never the best point, and enters the interpolation only through the quadratic fit that
+// ignores its slope (covkernel.cpp:532-536,556-560,572-573): its gradient is never read.  Same for a NaN/Inf probe
+// (bisected).  With an objective whose value does not depend on which half is called, the trajectory is the
+// default one probe for probe (tests/test_host_logic.py).  Opt-in: the default entry points keep the
+// reference's "both at every probe" (covkernel.cpp:500-501,585-586).
+//
 // Pure host code: no device calls.  The objective is a callback so the same loop drives one
 // expert, the experts of one GPU, or an all-reduced sum over ranks.
 #include <cfloat>
@@ -31,9 +40,18 @@ inline bool any_nan(const Vec3& a) { return std::isnan(a[0]) || std::isnan(a[1])
 class Probe {   // evaluates the objective and keeps the optional trace
 public:
     Probe(cugp_objective_fn fn, void* ctx, double* trace, int cap) : fn_(fn), ctx_(ctx), trace_(trace), cap_(cap) {}
-    void at(const Vec3& th, double& f, Vec3& g)
+    Probe(cugp_value_fn vf, cugp_gradient_fn gf, void* ctx, double* trace, int cap)
+        : vf_(vf), gf_(gf), ctx_(ctx), trace_(trace), cap_(cap) {}
+    // fref: the value the current line search started from (a probe above it never needs its gradient)
+    void at(const Vec3& th, double& f, Vec3& g, double fref)
     {
-        fn_(ctx_, th.v, &f, g.v);
+        if (fn_) {
+            fn_(ctx_, th.v, &f, g.v);
+        } else {
+            vf_(ctx_, th.v, &f);
+            if (std::isnan(f) || std::isinf(f) || f > fref) g = Vec3{{0.0, 0.0, 0.0}};   // never read (see header)
+            else { gf_(ctx_, th.v, g.v); ++grads_; }
+        }
         if (trace_ && count_ < cap_) {
             double* r = trace_ + 4 * (long)count_;
             r[0] = th[0]; r[1] = th[1]; r[2] = th[2]; r[3] = f;
@@ -41,8 +59,12 @@ public:
         ++count_;
     }
     int count() const { return count_; }
+    int grads() const { return fn_ ? count_ : grads_; }
 private:
-    cugp_objective_fn fn_;
+    cugp_objective_fn fn_ = nullptr;
+    cugp_value_fn vf_ = nullptr;
+    cugp_gradient_fn gf_ = nullptr;
+    int grads_ = 0;
     void* ctx_;
     double* trace_;
     int cap_;
@@ -51,20 +73,40 @@ private:
 
 }  // namespace
 
+static int cg_loop(Probe& probe, double theta[3], int budget);
+
 extern "C" int cugp_cg_minimize(cugp_objective_fn fn, void* ctx, double theta[3], int budget, double* trace,
                                 int trace_cap, int* nevals)
 {
     if (!fn || !theta || budget < 0) return CUGP_ERR_INVALID;
+    Probe probe(fn, ctx, trace, trace_cap);
+    const int rc = cg_loop(probe, theta, budget);
+    if (nevals) *nevals = probe.count();
+    return rc;
+}
+
+extern "C" int cugp_cg_minimize_sparing(cugp_value_fn value, cugp_gradient_fn gradient, void* ctx, double theta[3],
+                                        int budget, double* trace, int trace_cap, int* nevals, int* ngrads)
+{
+    if (!value || !gradient || !theta || budget < 0) return CUGP_ERR_INVALID;
+    Probe probe(value, gradient, ctx, trace, trace_cap);
+    const int rc = cg_loop(probe, theta, budget);
+    if (nevals) *nevals = probe.count();
+    if (ngrads) *ngrads = probe.grads();
+    return rc;
+}
+
+static int cg_loop(Probe& probe, double theta[3], int budget)
+{
     // constants: covkernel.cpp:407-411
     const double kInt = 0.1, kExt = 3.0, kRatio = 10, kSig = 0.1, kRho = kSig / 2;
     const int kMaxPerSearch = 20;
     const int n = budget;
 
-    Probe probe(fn, ctx, trace, trace_cap);
     Vec3 X{{theta[0], theta[1], theta[2]}};
     Vec3 df0, df3, s;
     double f0;
-    probe.at(X, f0, df0);                    // covkernel.cpp:438-439
+    probe.at(X, f0, df0, INFINITY);          // covkernel.cpp:438-439
     s = neg(df0);
     df3 = df0;
     double d0 = -dot(s, s);
@@ -83,7 +125,7 @@ extern "C" int cugp_cg_minimize(cugp_objective_fn fn, void* ctx, double theta[3]
             bool ok = false;
             while (!ok && left > 0) {
                 --left; ++i;
-                probe.at(axpy(X, s, x3), f3, df3);
+                probe.at(axpy(X, s, x3), f3, df3, f0);
                 if (!std::isnan(f3) && !std::isinf(f3) && !any_nan(df3)) ok = true;
                 else x3 = (x2 + x3) / 2;     // non-PD covariance comes back NaN: halve the step
             }
@@ -114,7 +156,7 @@ extern "C" int cugp_cg_minimize(cugp_objective_fn fn, void* ctx, double theta[3]
             if (std::isnan(x3) || std::isinf(x3)) x3 = (x2 + x4) / 2;
             const double hi = x4 - kInt * (x4 - x2), lo = x2 + kInt * (x4 - x2);
             x3 = std::fmax(std::fmin(x3, hi), lo);
-            probe.at(axpy(X, s, x3), f3, df3);
+            probe.at(axpy(X, s, x3), f3, df3, f0);
             if (f3 < bestF) { bestX = axpy(X, s, x3); bestF = f3; bestG = df3; }
             --left; ++i;
             d3 = dot(df3, s);
@@ -143,7 +185,6 @@ extern "C" int cugp_cg_minimize(cugp_objective_fn fn, void* ctx, double theta[3]
         }
     }
     theta[0] = X[0]; theta[1] = X[1]; theta[2] = X[2];
-    if (nevals) *nevals = probe.count();
     return CUGP_OK;
 }
 
@@ -161,7 +202,7 @@ extern "C" int cugp_rprop_minimize(cugp_objective_fn fn, void* ctx, double theta
     for (int it = 0; it < iters; ++it) {
         Vec3 g, gscratch;
         double fscratch, f;
-        probe.at(p, fscratch, g);                      // gradient at the current point (:369)
+        probe.at(p, fscratch, g, INFINITY);            // gradient at the current point (:369)
         for (int j = 0; j < 3; j++) prev[j] = prev[j] * g[j];
         for (int j = 0; j < 3; j++) {
             if (prev[j] > 0) {
@@ -175,7 +216,7 @@ extern "C" int cugp_rprop_minimize(cugp_objective_fn fn, void* ctx, double theta
         }
         prev = g;
         if (std::sqrt(dot(prev, prev)) < eps_stop) break;
-        probe.at(p, f, gscratch);                      // likelihood at the stepped point (:393)
+        probe.at(p, f, gscratch, INFINITY);            // likelihood at the stepped point (:393)
         const double lik = -f;
         if (lik > best) { best = lik; best_p = p; }
     }

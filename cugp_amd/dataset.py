@@ -50,7 +50,11 @@ def load_chunk(inputs_path, labels_path, rows=None, cache_dir=None):
         n = min(X.shape[0], y.shape[0])
         X, y = X[:n], y[:n]
         try:
-            np.savez(cpath, X=X, y=y)
+            # several ranks may parse the same chunk at once (every rank loads chunk 0's held-out rows): write to
+            # a private temporary and rename, so a reader never sees a half-written archive
+            tmp = "%s.%d.tmp.npz" % (cpath, os.getpid())
+            np.savez(tmp, X=X, y=y)
+            os.replace(tmp, cpath)
         except OSError:
             pass                                   # read-only location: just skip the cache
     if rows is not None:

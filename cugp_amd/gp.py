@@ -167,6 +167,15 @@ class Covsum:
         check(capi.lib().cugp_cg_solve(self._h, budget, ptr(tr), tr.shape[0], C.byref(ne)))
         return tr[: ne.value]
 
+    def cg_solve_sparing(self, X=None, y=None, budget=100):
+        """Opt-in: the same line search, but the gradient (two thirds of an evaluation) only where the search reads
+        it.  -> (trace, gradient evaluations made)."""
+        self._bind(X, y)
+        tr = np.zeros((4 * budget + 8, 4))
+        ne, ng = C.c_int(), C.c_int()
+        check(capi.lib().cugp_cg_solve_sparing(self._h, budget, ptr(tr), tr.shape[0], C.byref(ne), C.byref(ng)))
+        return tr[: ne.value], ng.value
+
     def rprop_solve(self, X=None, y=None, iters=100):
         self._bind(X, y)
         tr = np.zeros((2 * iters + 8, 4))
@@ -325,6 +334,24 @@ def cg_minimize(fn, theta, budget=100):
     check(capi.lib().cugp_cg_minimize(capi.OBJECTIVE(cb), None, ptr(th), budget, ptr(tr), tr.shape[0],
                                       C.byref(ne)))
     return th, tr[: ne.value]
+
+
+def cg_minimize_sparing(value_fn, gradient_fn, theta, budget=100):
+    """Evaluation-sparing CG on Python callbacks value_fn(theta)->f, gradient_fn(theta)->g.
+    -> (theta, trace, gradient evaluations made)."""
+    def vf(_ctx, th, f):
+        f[0] = value_fn(np.array([th[0], th[1], th[2]]))
+
+    def gf(_ctx, th, g):
+        gv = gradient_fn(np.array([th[0], th[1], th[2]]))
+        for i in range(3):
+            g[i] = gv[i]
+    th = f64(theta).copy()
+    tr = np.zeros((4 * budget + 8, 4))
+    ne, ng = C.c_int(), C.c_int()
+    check(capi.lib().cugp_cg_minimize_sparing(capi.VALUE_FN(vf), capi.GRADIENT_FN(gf), None, ptr(th), budget,
+                                              ptr(tr), tr.shape[0], C.byref(ne), C.byref(ng)))
+    return th, tr[: ne.value], ng.value
 
 
 def rprop_minimize(fn, theta, iters=100):

@@ -132,6 +132,16 @@ int cugp_cg_minimize(cugp_objective_fn fn, void *ctx, double theta[3], int budge
                      int *nevals);
 int cugp_rprop_minimize(cugp_objective_fn fn, void *ctx, double theta[3], int iters, double *trace, int trace_cap,
                         int *nevals);
+/* Opt-in, evaluation-sparing form of the same loop: the objective comes in two halves, the value
+ * and -- only where the line search can use it -- the gradient at the point of the last value call.  A probe whose
+ * value is above the line search's starting value (or NaN/Inf) never has its gradient read by covkernel.cpp:405-647,
+ * so it is not computed: on the GPU that probe costs the factorisation only (N^3/3 instead of N^3).  *ngrads <-
+ * gradient evaluations made.  The default entry points keep the reference's "both at every probe". */
+typedef void (*cugp_value_fn)(void *ctx, const double theta[3], double *f);
+typedef void (*cugp_gradient_fn)(void *ctx, const double theta[3], double g[3]);
+int cugp_cg_minimize_sparing(cugp_value_fn value, cugp_gradient_fn gradient, void *ctx, double theta[3], int budget,
+                             double *trace, int trace_cap, int *nevals, int *ngrads);
+int cugp_cg_solve_sparing(cugp_gp *gp, int budget, double *trace, int trace_cap, int *nevals, int *ngrads);
 int cugp_cg_solve(cugp_gp *gp, int budget, double *trace, int trace_cap, int *nevals);
 int cugp_rprop_solve(cugp_gp *gp, int iters, double *trace, int trace_cap, int *nevals);
 

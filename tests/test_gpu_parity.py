@@ -667,3 +667,25 @@ def test_second_device_after_first(gp_mod, oracle):
         ll, gr = g.loglik_grad(X, y)
         assert ll_close(ll, llo) and vec_close(gr, gro)
         g.close()
+
+
+def test_cg_sparing_on_the_gpu(gp_mod, si128, golden_si128):
+    """cugp_cg_solve_sparing: value-only probes (factorisation + solve) and gradients continued from the valid
+    factor.  Ends where the reference's run ends (the value half rounds differently from the combined evaluation,
+    so probe-for-probe identity is not claimed), with fewer gradient evaluations than probes."""
+    X, y = si128
+    gold = golden_si128["cg"][0]
+    g = gp_mod.Covsum(*X.shape)
+    g.set_loghyperparam(gold["hp0"])
+    tr, ng = g.cg_solve_sparing(X, y)
+    final = g.get_loghyperparam()
+    assert np.allclose(final, gold["final_hp"], atol=2e-4), (final, gold["final_hp"])
+    assert abs(g.compute_loglikelihood() - gold["final_ll"]) <= 1e-5
+    assert 0 < ng < tr.shape[0]
+    # continuing from a valid factor gives the gradient of the combined evaluation
+    g.set_loghyperparam(HP_DENSE)
+    ll = g.compute_loglikelihood()                     # factor only
+    gr = g.compute_gradient_loghyperparam()            # continued: L^-1, K^-1, traces
+    c = golden_si128["cases"][2]
+    assert ll_close(ll, c["ll"]) and vec_close(gr, c["grad"])
+    g.close()

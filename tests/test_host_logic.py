@@ -17,7 +17,7 @@ from conftest import HP_BCM, ROOT
 def test_header_symbols_all_exported_and_bound():
     text = open(os.path.join(ROOT, "include", "cugp.h")).read()
     declared = set(re.findall(r"\b(cugp_[A-Za-z0-9_]+)\s*\(", text))
-    declared -= {"cugp_objective_fn"}
+    declared -= {"cugp_objective_fn", "cugp_value_fn", "cugp_gradient_fn"}
     lib = capi.lib()
     missing = [n for n in sorted(declared) if not hasattr(lib, n)]
     assert not missing, missing
@@ -180,3 +180,26 @@ def test_potrf_plan_covers_every_update_exactly_once_in_order():
         for near in (1, 40, 300, 700, 5000):
             for nt in list(range(2, 30)) + [40, 63, 64, 79]:
                 _replay_potrf_plan(nt, P, near)
+
+
+def test_cg_sparing_takes_the_default_trajectory_with_fewer_gradients(oracle, si128):
+    """Opt-in evaluation-sparing CG: with an objective whose value does not depend on which half is called, every
+    probe point and value equals the default loop's (covkernel.cpp:405-647), and probes above the line search's
+    starting value cost no gradient."""
+    X, y = si128
+    Xs, ys = X[:48], y[:48]
+    calls = {"g": 0}
+
+    def value(th):
+        return -oracle.loglik(Xs, ys, th)
+
+    def gradient(th):
+        calls["g"] += 1
+        return oracle.grad(Xs, ys, th)
+
+    th0, tr0 = gp.cg_minimize(lambda th: (value(th), oracle.grad(Xs, ys, th)), HP_BCM, 60)
+    th1, tr1, ng = gp.cg_minimize_sparing(value, gradient, HP_BCM, 60)
+    assert np.array_equal(tr0, tr1) and np.array_equal(th0, th1)
+    assert ng == calls["g"] and ng <= tr1.shape[0]
+    print("sparing CG: %d probes, %d gradients" % (tr1.shape[0], ng))
+    assert ng < tr1.shape[0]                          # this run has rejected probes (f above the starting value)

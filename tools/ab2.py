@@ -17,7 +17,7 @@ import cugp_amd.gp as gp                                  # noqa: E402
 from cugp_amd import capi                                 # noqa: E402
 from conftest import synth                                # noqa: E402
 
-DEFAULT = {0: 768, 1: 1200, 2: 384, 3: -1, 4: 511, 5: 1, 6: 1, 7: 1 << 20, 8: 4, 9: 700, 10: 1 << 20, 11: 32, 12: 1, 13: 1, 14: 0, 15: 0}
+DEFAULT = {0: 768, 1: 1200, 2: 384, 3: -1, 4: 511, 5: 1, 6: 1, 7: 1 << 20, 8: 1, 9: 700, 10: 1 << 20, 11: 32, 12: 1, 13: 1, 14: 0, 15: 0, 16: 0, 17: 256, 18: 1536}
 n = int(sys.argv[1])
 names = sys.argv[2:] or ["base"]
 variants = [{} if a == "base" else dict((int(k), int(v)) for k, v in (kv.split("=") for kv in a.split(","))) for a in names]
@@ -37,20 +37,25 @@ g.set_profiling(1)
 hp = np.array([np.log(3.0), 0.0, np.log(0.1)])
 res = [dict(wall=[], potrf=[], total=[], la0=[], la3=[]) for _ in variants]
 vals = [None] * len(variants)
-for rnd in range(rounds + 1):
-    for vi, var in enumerate(variants):
-        apply(var)
-        g.set_loghyperparam(hp + (1e-4 * rnd if rnd else 0.0) + (1e-6 * vi if rnd else 0.0))
-        t0 = time.perf_counter()
-        ll, gr = g.loglik_grad()
-        t1 = time.perf_counter()
-        ph = g.phase_ms()
-        if rnd == 0:
-            vals[vi] = (ll, gr)
-            continue
-        res[vi]["wall"].append((t1 - t0) * 1e3)
-        res[vi]["potrf"].append(ph["potrf"])
-        res[vi]["total"].append(ph["total"])
+seq = os.environ.get("AB_SEQ", "0") != "0"       # variant-major order: for keys that rebuild streams when they change
+order = ([(rnd, vi) for vi in range(len(variants)) for rnd in range(-1, rounds + 1)] if seq
+         else [(rnd, vi) for rnd in range(rounds + 1) for vi in range(len(variants))])
+for rnd, vi in order:
+    var = variants[vi]
+    apply(var)
+    g.set_loghyperparam(hp + (1e-4 * rnd if rnd > 0 else 0.0) + (1e-6 * vi if rnd > 0 else 0.0) - (1e-5 if rnd < 0 else 0.0))
+    t0 = time.perf_counter()
+    ll, gr = g.loglik_grad()
+    t1 = time.perf_counter()
+    ph = g.phase_ms()
+    if rnd < 0:
+        continue                                  # warm-up after a switch (sequential mode)
+    if rnd == 0:
+        vals[vi] = (ll, gr)
+        continue
+    res[vi]["wall"].append((t1 - t0) * 1e3)
+    res[vi]["potrf"].append(ph["potrf"])
+    res[vi]["total"].append(ph["total"])
 if la:
     for vi, var in enumerate(variants):
         apply(var)

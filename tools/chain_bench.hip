@@ -50,13 +50,12 @@ int main()
     printf("potf2 (128x128 diagonal block): %.2f us (incl. %.2f us restore copy)\n", t_potf2, t_copy);
     unsigned long long st[64];
     hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof st);
-    printf("  stamps (cycles): load %llu | micro_factor0 %llu\n", st[1] - st[0], st[2] - st[1]);
+    printf("  stamps (cycles): load %llu | panel factor 0 %llu\n", st[1] - st[0], st[2] - st[1]);
     for (int jb = 0; jb < 7; jb++)
-        printf("  jb=%d: wait+subst(B) %llu  diag-update %llu  micro_factor %llu\n", jb,
-               st[3 + 3 * jb] - (jb ? st[5 + 3 * (jb - 1)] : st[2]), st[4 + 3 * jb] - st[3 + 3 * jb],
-               st[5 + 3 * jb] - st[4 + 3 * jb]);
-    printf("  tail wait %llu | store+last inverse %llu | logdet %llu | 64x64 inverses %llu | total %llu cycles\n",
-           st[30] - st[23], st[31] - st[30], st[32] - st[31], st[33] - st[32], st[33] - st[0]);
+        printf("  jb=%d: update of column jb+1 %llu   panel factor jb+1 beside the rest of the update %llu\n", jb,
+               st[3 + 3 * jb] - (jb ? st[4 + 3 * (jb - 1)] : st[2]), st[4 + 3 * jb] - st[3 + 3 * jb]);
+    printf("  store of the off-diagonal tiles %llu | logdet %llu | 64x64 inverses %llu | total %llu cycles\n", st[31] - st[30],
+           st[32] - st[31], st[33] - st[32], st[33] - st[0]);
 
     auto trsm2 = [](void* p) { Ctx* c = (Ctx*)p; launch_trsm_inv64(c->A, c->d64, c->n, 0, c->nt, 0); };
     printf("trsm_inv64 (%d strips): %.2f us\n", (nt - 1) * 8, timeit(trsm2, &c, 50));
