@@ -74,17 +74,13 @@ struct cugp_gp {
     hipStream_t aux = nullptr;      // ... except the inverse blocks that run beside the factorisation (fork/join by events):
     hipStream_t aux2 = nullptr;     // aux = the large products, aux2 = each block's own small inverse,
     hipStream_t lq = nullptr;       // lq = each block's share of K^-1 (beside the next block's bordering)
-    hipStream_t wide = nullptr;     // look-ahead Cholesky: the K = P*128 trailing updates beside the panel chain
-    hipStream_t chain = nullptr;    // ... and the panel chain itself, on its OWN compute units (CU-masked streams: a
-    hipStream_t widem = nullptr;    //     latency-bound chain kernel sharing a CU with MFMA tile products runs 3-5x slower)
-    int chain_cus = -1;             // compute units the masked pair was created for
+    hipStream_t wide = nullptr;     // two-speed Cholesky: optional stream of the wide passes (TUNE_WIDE_STREAM)
     int inv_reserve = -1;           // compute units the inverse streams (aux, aux2, lq) were created to stay off
-    hipEvent_t cfork = nullptr, cjoin = nullptr;   // main -> chain at the start of a factorisation, chain -> main at its end
     std::vector<hipEvent_t> bev;    // fork events, one per inverse block, + the join event (last)
     std::vector<hipEvent_t> oev;    // "block's own inverse done" events (aux2 -> aux)
     std::vector<hipEvent_t> lev;    // "block's inverse rows final" events (aux -> lq) + lq's join event (last)
     std::vector<hipEvent_t> pnev;   // "panel p factored" (main -> wide)
-    std::vector<hipEvent_t> wev;    // "wide update of panel p reached the next panel's look-ahead columns" (wide -> main) + join (last)
+    std::vector<hipEvent_t> wev;    // "wide pass of panel p done" (wide -> main) + join (last)
     double *dX = nullptr, *dy = nullptr, *dA = nullptr, *dT = nullptr, *dU = nullptr, *dKinv = nullptr;
     double *dz = nullptr, *dalpha = nullptr, *dw = nullptr, *d16 = nullptr, *dlogdet = nullptr, *dpart = nullptr, *d64 = nullptr;
     double* dout = nullptr;
@@ -287,29 +283,6 @@ StepPlan plan_step(int nt, int P, int near, int kb)
     return sp;
 }
 
-// The look-ahead factorisation runs its panel chain on `ncu` compute units of its own and the wide updates on
-// the others (hipExtStreamCreateWithCUMask; measured here: a 16-CU stream and its complement do not disturb each
-// other, while a chain kernel sharing CUs with tile products ran 3-5x slower and a prioritised stream still waited
-// for free workgroup slots).  Mask bit i is compute unit i in the runtime's order (dealt round-robin over the
-// 8 XCDs), so the chain gets ncu/8 CUs on every XCD.  (Re)created when the tuning changes.
-int ensure_partition_streams(cugp_gp* g, int ncu)
-{
-    if (g->chain && g->chain_cus == ncu) return CUGP_OK;
-    if (g->chain) { (void)hipStreamSynchronize(g->chain); (void)hipStreamDestroy(g->chain); g->chain = nullptr; }
-    if (g->widem) { (void)hipStreamSynchronize(g->widem); (void)hipStreamDestroy(g->widem); g->widem = nullptr; }
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, g->device));
-    const int total = prop.multiProcessorCount;
-    if (ncu < 8 || ncu > total - 8) return fail(CUGP_ERR_INVALID, "chain compute units out of range");
-    const int words = (total + 31) / 32;
-    std::vector<uint32_t> mc(words, 0u), mw(words, 0u);
-    for (int i = 0; i < total; i++) (i < ncu ? mc : mw)[i / 32] |= 1u << (i % 32);
-    HIPCHK(hipExtStreamCreateWithCUMask(&g->chain, (uint32_t)words, mc.data()));
-    HIPCHK(hipExtStreamCreateWithCUMask(&g->widem, (uint32_t)words, mw.data()));
-    g->chain_cus = ncu;
-    return CUGP_OK;
-}
-
 // The streams of the inverse blocks may be confined to all but `reserve` compute units (hipExtStreamCreateWithCUMask):
 // beside a saturated chip the factorisation's launches (panel solve, step kernel with the diagonal block inside)
 // waited 100-250 us per step for workgroup slots held by the inverse's long tiles; with a few CUs the inverse
@@ -388,17 +361,9 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false)
     const int P = panel_width(g);
     const int near = g_tune[TUNE_NEAR_TILES];
     if (w > 0 && (rc = ensure_inverse_streams(g))) return rc;
-    // streams: classic form -- everything on the handle's stream; look-ahead form -- the chain and the wide
-    // updates on disjoint sets of compute units (or, partition off, the chain on the handle's stream)
+    // everything on the handle's stream; the wide passes optionally on a stream of their own (the step launch
+    // that follows still waits for them: that form only moves them to another hardware queue)
     hipStream_t m = g->stream, wq = g_tune[TUNE_WIDE_STREAM] != 0 ? g->wide : g->stream;
-    const int ncu = P > 1 && g_tune[TUNE_WIDE_STREAM] != 0 ? g_tune[TUNE_CHAIN_CUS] : 0;
-    if (ncu > 0) {
-        if ((rc = ensure_partition_streams(g, ncu))) return rc;
-        m = g->chain;
-        wq = g->widem;
-        HIPCHK(hipEventRecord(g->cfork, g->stream));
-        HIPCHK(hipStreamWaitEvent(m, g->cfork, 0));
-    }
     int nblk = 0, done = 0;                                 // blocks forked so far, block rows handed over
     bool wide_used = false;
     g->eval_seq++;
@@ -453,11 +418,6 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false)
     if (wide_used && wq != m) {                             // (every wide launch was already waited for; this join
         HIPCHK(hipEventRecord(g->wev.back(), wq));          //  keeps the stream graph closed)
         HIPCHK(hipStreamWaitEvent(m, g->wev.back(), 0));
-    }
-    if (m != g->stream) {                                   // back to the handle's stream
-        HIPCHK(hipEventRecord(g->cjoin, m));
-        HIPCHK(hipStreamWaitEvent(g->stream, g->cjoin, 0));
-        m = g->stream;
     }
     if (mark && (rc = phase_mark(g, 2))) return rc;         // end of the factorisation on the main stream
     if (w > 0) {
@@ -678,8 +638,6 @@ int cugp_create_padded(int n, int d, int device, int npad_min, cugp_gp** out)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->lq, hipStreamNonBlocking);
     g->inv_reserve = 0;             // (ensure_inverse_streams rebuilds them CU-masked when asked to)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->wide, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->cfork, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&g->cjoin, hipEventDisableTiming);
     for (std::vector<hipEvent_t>* v : {&g->bev, &g->oev, &g->lev, &g->pnev, &g->wev}) {
         v->assign((size_t)g->nt + 2, nullptr);
         for (size_t i = 0; i < v->size() && e == hipSuccess; i++) e = hipEventCreateWithFlags(&(*v)[i], hipEventDisableTiming);
@@ -717,8 +675,6 @@ int cugp_destroy(cugp_gp* g)
     if (g->aux2) (void)hipStreamSynchronize(g->aux2);
     if (g->lq) (void)hipStreamSynchronize(g->lq);
     if (g->wide) (void)hipStreamSynchronize(g->wide);
-    if (g->chain) (void)hipStreamSynchronize(g->chain);
-    if (g->widem) (void)hipStreamSynchronize(g->widem);
     double* bufs[] = {g->dX, g->dy, g->dA, g->dT, g->dU, g->dKinv, g->dz, g->dalpha, g->dw, g->d16, g->dlogdet,
                       g->dpart, g->dout, g->d64};
     for (double* p : bufs)
@@ -740,10 +696,6 @@ int cugp_destroy(cugp_gp* g)
     if (g->aux2) (void)hipStreamDestroy(g->aux2);
     if (g->lq) (void)hipStreamDestroy(g->lq);
     if (g->wide) (void)hipStreamDestroy(g->wide);
-    if (g->chain) (void)hipStreamDestroy(g->chain);
-    if (g->widem) (void)hipStreamDestroy(g->widem);
-    if (g->cfork) (void)hipEventDestroy(g->cfork);
-    if (g->cjoin) (void)hipEventDestroy(g->cjoin);
     if (g->stream) (void)hipStreamDestroy(g->stream);
     delete g;
     return CUGP_OK;

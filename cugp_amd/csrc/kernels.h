@@ -22,8 +22,8 @@ enum { TUNE_LAUUM_WM2_MAX = 0,   // K^-1 product: use 64x64 tiles when there are
        TUNE_PANEL_MIN_NT = 11,   // ... only from this many tiles on (small matrices are bound by the chain alone)
        TUNE_LAUUM_STREAM = 12,   // the K^-1 share of an inverse block on its own stream beside the next block's bordering (1) or behind it (0)
        TUNE_STEP_STREAM = 13,    // two-speed step kernel: non-temporal accesses to the C tiles (1) or plain ones (0)
-       TUNE_CHAIN_CUS = 14,      // experimental two-stream form: compute units reserved for the panel chain (CU-masked streams); 0 = no partition
-       TUNE_WIDE_STREAM = 15,    // wide updates on the handle's stream (0) or on their own stream beside the next panel's chain (1, experimental)
+       TUNE_RESERVED_14 = 14,    // (unused)
+       TUNE_WIDE_STREAM = 15,    // wide passes on the handle's stream (0) or through a stream of their own (1: another hardware queue, same order)
        TUNE_INVERSE_RESERVE = 16, // compute units the inverse-block streams stay off (CU-masked), so the factorisation's launches always find free slots; 0 = no mask
        TUNE_SPLIT_REM_MAX = 17,  // uniform-K launches (block-wise K^-1 share, bordering, wide update): a last round of at most this many tiles runs as 64x64 quarters
        TUNE_STEP_QUARTER_MAX = 18, // step kernel: launches of at most this many 64x64 workgroups run ALL their tiles as quarters (chain-bound tail)
