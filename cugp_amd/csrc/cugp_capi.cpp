@@ -262,6 +262,18 @@ int far_boundary(int nt, int P, int near, int p)
         int f = k0 + 1 + wc;
         if (f < (q + 1) * P + 1) f = (q + 1) * P + 1;
         if (f > nt) f = nt;
+        // the far pass costs whole rounds of 512 tile slots (134 us each at K = 512): move the boundary up to three
+        // columns out if that makes its tri(nt - f) tiles end close to a full round
+        {
+            int best = f;
+            double bw = 2.0;
+            for (int c = f; c <= f + 3 && c < nt; c++) {
+                const int tiles = tri_tiles(nt - c), rem = tiles % 512;
+                const double waste = rem == 0 ? 0.0 : (512.0 - rem) / 512.0 / (tiles / 512 + 1);   // idle share of the pass
+                if (waste < bw - 0.02) { bw = waste; best = c; }
+            }
+            f = best;
+        }
         if (f > F) F = f;
     }
     return F;
@@ -314,7 +326,7 @@ int panel_width(const cugp_gp* g)
 {
     int P = g_tune[TUNE_PANEL];
     if (P < 2 || g->nt < g_tune[TUNE_PANEL_MIN_NT] || g->nt < 3 * P) return 1;
-    return P > 16 ? 16 : P;
+    return P > 32 ? 32 : P;
 }
 
 // one timed launch (profiling level 2): event pair + bookkeeping

@@ -1252,35 +1252,40 @@ __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, in
 // ------------------------------------------------------------------------------------------
 // Wide trailing update (look-ahead Cholesky): A(ti,tj) -= sum_{k in [k0, k0+kw)} L(ti,k) L(tj,k)^T for the tile
 // columns tj in [ca, cb), ti >= tj -- ONE pass over the C tiles with K = kw*128 (the tile product costs a fixed
-// ~12 us per C tile + 30.5 us per 128 of K: 50 TF/s at K=128, 67 at K=512).  Runs on its own stream beside
-// the panel chain (potf2 / panel solve / narrow k_syrk_step), so the grid is BOUNDED (gridDim.x workgroups walk
-// the tile list with a stride): the chain's launches always find free workgroup slots instead of queueing
-// behind a full wave of 134-us tiles.  gridDim.x is a multiple of 8, so a workgroup stays on one XCD and
-// every XCD walks one contiguous run of the (row-major) tile list: neighbours share panel rows in its L2.
+// ~12 us per C tile + 30.5 us per 128 of K: 50 TF/s at K=128, 66 at K=512 when the tiles fill whole rounds of
+// the 512 workgroup slots).  One workgroup per tile; a small last round runs as 64x64 quarters.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void k_syrk_wide(double* __restrict__ A, int ld, int k0, int kw, int ca,
-                                                      int cb, int ntiles, int rev,
+                                                      int cb, int ntiles, int nfull, int rev,
                                                       const ExpertPtrs* __restrict__ bt)
 {
     if (bt) A = bt[blockIdx.y].A;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __builtin_amdgcn_s_setprio(1);
-    const int G = gridDim.x, xg = blockIdx.x & 7;
-    const int xq = ntiles >> 3, xr = ntiles & 7;
-    const int run0 = xg < xr ? xg * (xq + 1) : xr * (xq + 1) + (xg - xr) * xq;   // first tile of my XCD's run
-    const int runlen = xq + (xg < xr ? 1 : 0);
-    for (int r = blockIdx.x >> 3; r < runlen; r += G >> 3) {
+    if ((int)blockIdx.x >= nfull) {
+        // the last, partly empty round of the launch as 64x64 quarters (split_round)
+        const int y = blockIdx.x - nfull;
         int ti, tj;
-        const int tlin = run0 + r;
-        trap_index(rev ? ntiles - 1 - tlin : tlin, cb - ca, ti, tj);
-        // (wave-uniform, but the sqrt of the index map runs on the vector unit: move the result back to SGPRs so
-        // the tile coordinates do not hold vector registers across the K loop)
-        const int i0 = __builtin_amdgcn_readfirstlane((ca + ti) * TILE), j0 = __builtin_amdgcn_readfirstlane((ca + tj) * TILE);
-        d4 acc[4][4];
+        trap_index(nfull + (y >> 2), cb - ca, ti, tj);
+        const int i0 = (ca + ti) * TILE + ((y >> 1) & 1) * 64, j0 = (ca + tj) * TILE + (y & 1) * 64;
+        d4 acc[2][2];
         tile_load<true>(A + (size_t)i0 * ld + j0, ld, acc);
         tile_nt<true>(A + (size_t)i0 * ld, ld, A + (size_t)j0 * ld, ld, k0 * TILE, (k0 + kw) * TILE, acc, smem);
         tile_store<true>(A + (size_t)i0 * ld + j0, ld, acc, 1.0);
+        return;
     }
+    // every XCD (workgroups are dealt round-robin over the 8 of them) walks one contiguous run of the row-major
+    // tile list: neighbours share panel rows in its L2
+    const int xg = blockIdx.x & 7;
+    const int xq = nfull >> 3, xr = nfull & 7;
+    const int tlin = (xg < xr ? xg * (xq + 1) : xr * (xq + 1) + (xg - xr) * xq) + (blockIdx.x >> 3);
+    int ti, tj;
+    trap_index(rev ? nfull - 1 - tlin : tlin, cb - ca, ti, tj);
+    const int i0 = (ca + ti) * TILE, j0 = (ca + tj) * TILE;
+    d4 acc[4][4];
+    tile_load<true>(A + (size_t)i0 * ld + j0, ld, acc);
+    tile_nt<true>(A + (size_t)i0 * ld, ld, A + (size_t)j0 * ld, ld, k0 * TILE, (k0 + kw) * TILE, acc, smem);
+    tile_store<true>(A + (size_t)i0 * ld + j0, ld, acc, 1.0);
 }
 
 // inverse of a 128x128 diagonal factor block from the two 64x64 inverses potf2 left in d64 (one doubling
@@ -1558,7 +1563,7 @@ __global__ __launch_bounds__(256) void k_predict_finish(const double* __restrict
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-int g_tune[TUNE_COUNT] = {768, 1200, 384, -1, 511, 1, 1, 1 << 20, 1, 700, 1 << 20, 32, 1, 1, 0, 0, 0, 256, 1536};   // defaults chosen by interleaved A/B runs (tools/ab.py)
+int g_tune[TUNE_COUNT] = {768, 1200, 384, -1, 511, 1, 1, 1 << 20, 16, 500, 1 << 20, 32, 1, 1, 0, 0, 0, 256, 1536};   // defaults chosen by interleaved A/B runs (tools/ab.py)
 
 static inline int tri_count(int n) { return n * (n + 1) / 2; }
 
@@ -1630,6 +1635,17 @@ void launch_trtri_diag(const double* A, int ld, int kb, int nblocks, const doubl
     hipLaunchKernelGGL(k_trtri_diag, dim3(nblocks, bt.count), dim3(256), TRTRI_LDS, s, A, ld, kb, d64, T, U, bt.tab);
 }
 
+// A launch of `tiles` uniform-ish 128x128 tiles fills the 512 workgroup slots round by round; a last round that is
+// mostly empty still costs a whole tile time (134 us at K = 512).  When the remainder is small its tiles run as
+// four 64x64 workgroups each instead: -> number of tiles launched whole (the rest are split).
+static int split_round(int tiles, int count)
+{
+    const int slots = 512 / (count > 0 ? count : 1) > 0 ? 512 / (count > 0 ? count : 1) : 1;
+    const int rem = tiles % slots;
+    if (tiles < slots || rem == 0 || rem > g_tune[TUNE_SPLIT_REM_MAX]) return tiles;
+    return tiles - rem;
+}
+
 static inline int trap_count(int m, int wcol)          // tiles (ti >= tj) of the first wcol columns of an m-triangle
 {
     return wcol >= m ? tri_count(m) : tri_count(wcol) + (m - wcol) * wcol;
@@ -1663,11 +1679,9 @@ int launch_syrk_wide(double* A, int ld, int nt, int k0, int kw, int ca, int cb, 
     if (ca >= cb || kw <= 0) return 0;
     set_big_lds();
     const int ntiles = trap_count(nt - ca, cb - ca);
-    int G = g_tune[TUNE_WIDE_GRID] & ~7;               // bounded grid: the panel chain keeps finding free slots
-    if (G < 8) G = 8;
-    if (G > ((ntiles + 7) & ~7)) G = (ntiles + 7) & ~7;
-    hipLaunchKernelGGL(k_syrk_wide, dim3(G, bt.count), dim3(256), GEMM_LDS, s, A, ld, k0, kw, ca, cb, ntiles, rev,
-                       bt.tab);
+    const int nfull = split_round(ntiles, bt.count);
+    hipLaunchKernelGGL(k_syrk_wide, dim3(nfull + 4 * (ntiles - nfull), bt.count), dim3(256), GEMM_LDS, s, A, ld, k0, kw, ca,
+                       cb, ntiles, nfull, rev, bt.tab);
     return ntiles;
 }
 
@@ -1694,17 +1708,6 @@ void launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, i
 
 // step 1 of the bordering, spread over time: add the k tiles [c0, c1) (a block of inverse rows that just
 // became final) to Wt(tj < c1, ti in [ra, ra+rw)) for ALL rows below the block
-// A launch of `tiles` uniform-ish 128x128 tiles fills the 512 workgroup slots round by round; a last round that is
-// mostly empty still costs a whole tile time (134 us at K = 512).  When the remainder is small its tiles run as
-// four 64x64 workgroups each instead: -> number of tiles launched whole (the rest are split).
-static int split_round(int tiles, int count)
-{
-    const int slots = 512 / (count > 0 ? count : 1) > 0 ? 512 / (count > 0 ? count : 1) : 1;
-    const int rem = tiles % slots;
-    if (tiles < slots || rem == 0 || rem > g_tune[TUNE_SPLIT_REM_MAX]) return tiles;
-    return tiles - rem;
-}
-
 void launch_trtri_border1(const double* L, double* T, double* U, int ld, int ra, int rw, int c0, int c1,
                           hipStream_t st, Batch bt)
 {

@@ -28,7 +28,7 @@ int main(int argc, char** argv)
     const int grids[] = {1 << 20, 512, 448, 1024};
     for (const Case& c : cases) {
         for (int G : grids) {
-            g_tune[TUNE_WIDE_GRID] = G;
+            (void)G;
             int tiles = launch_syrk_wide(A, n, nt, c.k0, c.kw, c.ca, c.cb, 0, 0);
             hipDeviceSynchronize();
             hipEventRecord(a);
