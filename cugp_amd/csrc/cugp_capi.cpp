@@ -93,6 +93,8 @@ struct cugp_gp {
     bool inverse_valid = false;    // T, U, Kinv, alpha hold the inverse quantities for (data, hp)
     bool pending = false, pending_grad = false;
     bool joined = true;            // no inverse blocks outstanding on `aux`
+    bool vec_early = false;        // record_eval: z = L^-1 y, alpha = L^-T z go behind the last block's bordering
+    bool vec_done = false;         // ... and were enqueued there
     const GroupCtx* grp = nullptr;  // non-null only inside cugp_group_eval
     double* pred_buf = nullptr;     // prediction scratch (test inputs, cross-covariance, its product with L^-T, results)
     size_t pred_cap = 0;            // ... in doubles, grow-only
@@ -213,6 +215,13 @@ int enqueue_inverse_block(cugp_gp* g, int a, int b, bool kinv, hipStream_t x, hi
     }
     // ... and these rows, now final, go into the Wt of every row below them
     if (b < g->nt) launch_trtri_border1(g->dA, g->dT, g->dU, ld, b, g->nt - b, a, b, x, B(g));
+    if (b == g->nt && g->vec_early) {
+        // L^-1 is complete: z = L^-1 y and alpha = L^-T z run here, beside / in front of the last share of K^-1,
+        // instead of after it on the main stream (~130 us at N = 8192)
+        launch_trmv_lower(g->dT, g->npad, g->npad, g->dy, g->dz, x, B(g));
+        launch_trmv_upper(g->dU, g->npad, g->npad, g->dz, g->dalpha, x, B(g));
+        g->vec_done = true;
+    }
     if (kinv && !lq) launch_lauum(g->dU, g->dKinv, ld, a, wb, x, B(g));
     return CUGP_OK;
 }
@@ -485,13 +494,19 @@ int record_eval(cugp_gp* g, bool want_grad, const HyperScalars* hd)
     if ((rc = phase_mark(g, 0))) return rc;
     launch_kbuild(g->dX, g->n, g->d, g->npad, h, g->dA, false, s, hd, B(g));
     if ((rc = phase_mark(g, 1))) return rc;
-    if ((rc = enqueue_potrf(g, want_grad, true))) return rc;   // + L^-1 and K^-1, block rows at a time beside it
+    g->vec_early = want_grad;
+    g->vec_done = false;
+    rc = enqueue_potrf(g, want_grad, true);                    // + L^-1 and K^-1, block rows at a time beside it
+    g->vec_early = false;
+    if (rc) return rc;
     if (want_grad) {
         if ((rc = join_inverse(g))) return rc;
         if ((rc = phase_mark(g, 3))) return rc;              // "trtri" phase = what is left of the inverse blocks
         if ((rc = phase_mark(g, 4))) return rc;
-        launch_trmv_lower(g->dT, g->npad, g->npad, g->dy, g->dz, s, B(g));        // z = L^-1 y
-        launch_trmv_upper(g->dU, g->npad, g->npad, g->dz, g->dalpha, s, B(g));    // alpha = L^-T z
+        if (!g->vec_done) {
+            launch_trmv_lower(g->dT, g->npad, g->npad, g->dy, g->dz, s, B(g));        // z = L^-1 y
+            launch_trmv_upper(g->dU, g->npad, g->npad, g->dz, g->dalpha, s, B(g));    // alpha = L^-T z
+        }
         launch_trace(g->dX, g->n, g->d, g->npad, h, g->dKinv, g->dalpha, g->dpart, s, hd, B(g));
         launch_finalize(g->dz, g->npad, g->n, g->dlogdet, g->nt, g->dpart, g->nblocks_trace, h, g->dout, s, hd, B(g));
     } else {
