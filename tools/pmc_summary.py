@@ -1,4 +1,4 @@
-"""Summarise rocprofv3 PMC passes (tools/pmc.sh) into profiles/r01_pmc_summary.json.
+"""Summarise rocprofv3 PMC passes (tools/pmc.sh) into profiles/r02_pmc_summary.json.
 FETCH_SIZE is doubled before use: on gfx950 it reports half the bytes of wide coalesced reads
 (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact for 16-byte-per-lane stores.  Units: KiB."""
 import collections
@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out")
-KERNELS = ("k_syrk_step", "k_lauum", "k_trtri_level", "k_trtri_border", "k_trtri_diag", "k_build", "k_trace", "k_potf2",
+KERNELS = ("k_syrk_step", "k_syrk_wide", "k_lauum", "k_trtri_level", "k_trtri_border", "k_trtri_diag", "k_build", "k_trace", "k_potf2",
            "k_trsm_inv64")
 
 
@@ -55,6 +55,6 @@ for k, v in sq.items():
 for k, d in out["kernels"].items():
     if "fetch_kib_raw" in d and "write_kib" in d and d.get("launches"):
         d["hbm_bytes_per_launch"] = (2.0 * d["fetch_kib_raw"] + d["write_kib"]) * 1024.0 / d["launches"]
-json.dump(out, open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json"), "w"), indent=1)
 for k, d in out["kernels"].items():
     print(k, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in d.items() if a != "sq"})
