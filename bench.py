@@ -244,6 +244,22 @@ def main():
                 out["roofline"] = roof("k_syrk_wide", "k_syrk_wide (Cholesky far trailing update, fp64 MFMA 16x16x4, "
                                        "K=128*panel per launch)", kw, iso_w if iso is not None else None)
                 out["roofline_step"] = step
+                # the two kernels of the trailing update together: their flop over the sum of their durations (every
+                # wide launch is timed, one step launch in 8: scale the step sample up)
+                fl = kw["flop"] + 8.0 * ks["flop"]
+                ms = kw["sum_ms"] + 8.0 * ks["sum_ms"]
+                tu = {"what": "k_syrk_wide + k_syrk_step together (N^3/3 flop of the factorisation)",
+                      "achieved": fl / (ms * 1e-3) / 1e12, "unit": "TFLOP/s", "peak": MFMA_F64_PEAK_TFLOPS,
+                      "wide_share_of_flop": kw["flop"] / fl}
+                tu["frac"] = tu["achieved"] / MFMA_F64_PEAK_TFLOPS
+                if iso is not None and iso["launches"] > 0 and iso_w["launches"] > 0:
+                    ia = (iso_w["flop"] + 8.0 * iso["flop"]) / ((iso_w["sum_ms"] + 8.0 * iso["sum_ms"]) * 1e-3) / 1e12
+                    tu["isolated_achieved"], tu["isolated_frac"] = ia, ia / MFMA_F64_PEAK_TFLOPS
+                out["roofline_trailing_update"] = tu
+                out["roofline"]["share_of_factorisation_flop"] = tu["wide_share_of_flop"]
+                out["roofline"]["dominant_by"] = ("flop of the factorisation; by time it is k_syrk_step, whose launches "
+                                                  "carry the latency-bound diagonal block: see roofline_step and "
+                                                  "roofline_trailing_update")
             else:
                 out["roofline"] = step
             out["roofline"]["whole_evaluation_frac"] = out["eval_tflops_n3"] / MFMA_F64_PEAK_TFLOPS
