@@ -4,10 +4,13 @@ unmodified (oracle/Makefile -> oracle/_ref), and against the reference's committ
 cuda_bettersinglenode_ver2/REF.  CPU only.  The restatement follows the reference operation for
 operation (no FMA contraction), so agreement is expected to the last bit; tolerances of a few ulp are
 left for libm differences across machines."""
+import json
+import os
+
 import numpy as np
 import pytest
 
-from conftest import HP_BCM
+from conftest import GOLDEN, HP_BCM
 
 TIGHT = dict(rtol=1e-13, atol=1e-13)
 
@@ -132,3 +135,19 @@ def test_degenerate_inputs(oracle):
     Kbad[2, 2] = -1.0
     q, ld = oracle.chol_and_det(Kbad, np.ones(3))
     assert np.isnan(ld)
+
+
+def test_oracle_on_si24000_shards(oracle):
+    """Config 5's data through the CPU restatement: two of the 16 shards of si24000 against the per-expert
+    log-likelihoods the reference's BCM printed (6 decimals), and the dense-hp gradient contribution stays finite.
+    (The full 16-shard sum and the 6000-/8192-/10000-row cases are GPU tests: the oracle needs minutes to hours there.)"""
+    p = os.path.join(GOLDEN, "golden_r2", "si24000_bcm16.json")
+    if not os.path.exists(p):
+        pytest.skip("golden_r2/si24000_bcm16.json not generated")
+    c = json.load(open(p))["cases"][0]
+    d = np.load(os.path.join(GOLDEN, "data_si24000.npz"))
+    for k in (0, 15):
+        X = np.ascontiguousarray(d["X"][1500 * k:1500 * (k + 1)])
+        y = np.ascontiguousarray(d["y"][1500 * k:1500 * (k + 1)])
+        ll = oracle.loglik(X, y, c["hp"])
+        assert abs(ll - c["ll_per_expert_6dp"][k]) <= 6e-7, (k, ll, c["ll_per_expert_6dp"][k])
