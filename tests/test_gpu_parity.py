@@ -689,3 +689,44 @@ def test_cg_sparing_on_the_gpu(gp_mod, si128, golden_si128):
     c = golden_si128["cases"][2]
     assert ll_close(ll, c["ll"]) and vec_close(gr, c["grad"])
     g.close()
+
+
+def test_sharded_bcm_device_rows_with_rccl_single_rank(tmp_path):
+    """The one-process-per-GPU layout on the one GPU of this box: a 1-rank NCCL (= RCCL) process group, the
+    per-expert rows written into the device tensor by cugp_bcm_loglik_grad_rows_device and all-reduced there.
+    (More ranks need more GPUs; the sharding / ordered sum itself is covered on 2 gloo ranks in
+    tests/test_distributed_gloo.py.)  Runs in a child process: a process group is process-global state."""
+    import subprocess, sys, textwrap
+    from conftest import ROOT
+    script = tmp_path / "rank0.py"
+    script.write_text(textwrap.dedent('''
+        import os, sys
+        import numpy as np, torch, torch.distributed as dist
+        sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+        from conftest import synth, HP_DENSE
+        from cugp_amd.bcm import ShardedBCM
+        import cugp_amd.gp as gp
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        X, y = synth(3 * 300, 5, seed=4)
+        experts = [(X[300 * k:300 * (k + 1)], y[300 * k:300 * (k + 1)]) for k in range(3)]
+        b = ShardedBCM(experts, rank=0, world=1, device=0, comm_device=torch.device("cuda", 0))
+        assert b._on_device
+        b._allreduce = lambda t: (dist.all_reduce(t, op=dist.ReduceOp.SUM), t)[1]     # force the collective at 1 rank
+        b.set_loghyper(HP_DENSE)
+        ll, g, per = b.loglik_grad()
+        ref = gp.BCM([300, 300, 300], 5, 0)
+        for k, (Xk, yk) in enumerate(experts):
+            ref.set_expert_data(k, Xk, yk)
+        ref.set_BCM_log_hyperparam(HP_DENSE)
+        ll0, g0, per0 = ref.loglik_grad()
+        assert ll == ll0 and np.array_equal(g, g0) and np.array_equal(per, per0), (ll, ll0, g, g0)
+        tr = b.cg_solve(budget=8)
+        assert np.all(np.isfinite(tr))
+        b.close(); ref.close()
+        dist.destroy_process_group()
+        print("RCCL_SINGLE_RANK_OK")
+        ''' % (ROOT, ROOT)))
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "RCCL_SINGLE_RANK_OK" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
