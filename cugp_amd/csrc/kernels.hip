@@ -2,8 +2,9 @@
 //
 // Path (reference file:line each kernel replaces):
 //   k_build        SE+noise covariance          cpp_serial_gp/covkernel.cpp:64-102, cuda_scalingdist/cuda_gp.cu:232-281
-//   potf2 / trsm / syrk   blocked right-looking Cholesky   common/matrixops.cpp:68-108,
-//                  cpp_matrixalgebra/blocked_cholesky.cpp:221-262, cuda_src/cuda_gp.cu:1237-1308
+//   potf2 / trsm / syrk_step / syrk_wide   blocked right-looking Cholesky (near window per step, far columns once per
+//                  panel)   common/matrixops.cpp:68-108, cpp_matrixalgebra/blocked_cholesky.cpp:221-262,
+//                  cuda_src/cuda_gp.cu:1237-1308
 //   trtri_*        L^-1 by recursive doubling   common/matrixops.cpp:330-340, cuda_src/cuda_gp.cu:1854-1915 (TMI)
 //   lauum          K^-1 = L^-T L^-1             common/matrixops.cpp:383-435, cuda_src/cuda_gp.cu:119-136
 //   trmv / trace / finalize   alpha, y'K^-1 y, log|K|, gradient traces   covkernel.cpp:118-129,162-263
