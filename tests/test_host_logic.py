@@ -176,8 +176,8 @@ def _replay_potrf_plan(nt, P, near):
 
 
 def test_potrf_plan_covers_every_update_exactly_once_in_order():
-    for P in (1, 2, 3, 4, 5, 8):
-        for near in (1, 40, 300, 700, 5000):
+    for P in (1, 2, 3, 4, 5, 8, 16, 32):                 # 16 / 500 is the shipped default
+        for near in (1, 40, 300, 500, 700, 5000):
             for nt in list(range(2, 30)) + [40, 63, 64, 79]:
                 _replay_potrf_plan(nt, P, near)
 
