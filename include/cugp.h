@@ -50,7 +50,7 @@ int cugp_create(int n, int d, int device, cugp_gp **out);
 int cugp_create_padded(int n, int d, int device, int npad_min, cugp_gp **out);
 int cugp_destroy(cugp_gp *gp);
 int cugp_dims(const cugp_gp *gp, int *n, int *d, int *npad);
-/* A gradient evaluation builds L^-1 and K^-1 block row by block row on two further streams while the
+/* A gradient evaluation builds L^-1 and K^-1 block row by block row on three further streams while the
  * factorisation is still running (its tail leaves most of the chip idle).  On by default; cugp_bcm_create
  * turns it off when several experts share the device.  No reference counterpart (the reference calls
  * cusolverDnDpotrf, then inverts: cuda_scalingdist/cuda_gp.cu:647-708). */
