@@ -730,3 +730,25 @@ def test_sharded_bcm_device_rows_with_rccl_single_rank(tmp_path):
         ''' % (ROOT, ROOT)))
     out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "RCCL_SINGLE_RANK_OK" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
+
+
+@pytest.mark.parametrize("n,ridge", [(384, 1e-6), (515, 1e-9)])
+def test_potrf_ill_conditioned(gp_mod, oracle, n, ridge):
+    """Covariance matrices along a CG trajectory reach cond(K) ~ 1e6 and beyond (sigma_n^2 -> 1e-3): the panel-form
+    diagonal block (v_rsq_f64 seed + one third-order step, substitution folded into the pivot loop, 16x16 inverses)
+    must stay backward stable there: L L^T reproduces K to rounding and L agrees with the CPU factor to
+    cond(K) * eps."""
+    rng = np.random.default_rng(n)
+    M = rng.standard_normal((n, n // 4))
+    K = M @ M.T + ridge * np.eye(n)                      # rank n/4 + ridge: cond ~ n / ridge
+    K = 0.5 * (K + K.T)
+    L = gp_mod.potrf(K)
+    assert np.all(np.isfinite(L))
+    assert np.max(np.abs(L @ L.T - K)) <= 1e-12 * np.max(np.abs(K))            # backward error
+    Lo = oracle.cholesky(K)
+    cond = np.linalg.cond(K)
+    assert np.max(np.abs(L - Lo)) <= 50 * cond * 2.2e-16 * np.max(np.abs(Lo))  # forward error ~ cond * eps
+    q, ld = gp_mod.chol_and_det(K, np.ones(n))
+    qo, ldo = oracle.chol_and_det(K, np.ones(n))
+    # (log|K| is a sum of logs of pivots as small as the ridge: its error scales with cond(K) * eps as well)
+    assert abs(ld - ldo) <= max(1e-9 * abs(ldo), 10 * cond * 2.2e-16) and abs(q - qo) <= 100 * cond * 2.2e-16 * abs(qo)
