@@ -752,3 +752,23 @@ def test_potrf_ill_conditioned(gp_mod, oracle, n, ridge):
     qo, ldo = oracle.chol_and_det(K, np.ones(n))
     # (log|K| is a sum of logs of pivots as small as the ridge: its error scales with cond(K) * eps as well)
     assert abs(ld - ldo) <= max(1e-9 * abs(ldo), 10 * cond * 2.2e-16) and abs(q - qo) <= 100 * cond * 2.2e-16 * abs(qo)
+
+
+@pytest.mark.parametrize("n", [2049, 4200])
+def test_results_do_not_depend_on_timing(gp_mod, n):
+    """Everything a block of inverse rows does is ordered on its streams and every tile sees its updates in a fixed
+    order (classic steps below 32 tiles, near window + far passes above): the same evaluation repeated -- whatever
+    the streams' relative timing -- returns the same bits, with the inverse beside the factorisation or after it."""
+    X, y = synth(n, d=6, seed=n)
+    hp = np.array([1.0, 0.2, -1.1])
+    g = gp_mod.Covsum(n, 6)
+    g.set_data(X, y)
+    seen = []
+    for it in range(4):
+        g.set_loghyperparam(hp + 1.0)                    # another point in between: nothing is cached
+        g.loglik_grad()
+        g.set_loghyperparam(hp)
+        ll, gr = g.loglik_grad()
+        seen.append((ll, tuple(gr)))
+    assert all(s == seen[0] for s in seen), seen
+    g.close()
