@@ -1,5 +1,6 @@
 """Three LL+grad evaluations at one size, no profiling events: run under `rocprofv3 --kernel-trace` and feed the
-kernel trace to tools/timeline_report.py.   python3 tools/timeline_run.py <n> [pipe [key=value ...]]"""
+kernel trace to tools/timeline_report.py.   python3 tools/timeline_run.py <n> [pipe [key=value ...]]
+TL_EXPERTS=K in the environment: a BCM of K experts over the n rows on one device instead of one expert."""
 import os
 import sys
 
@@ -19,10 +20,18 @@ for kv in sys.argv[3:]:                                   # further tuning keys 
     k, v = kv.split("=")
     capi.check(capi.lib().cugp_set_tuning(int(k), int(v)))
 X, y = synth(n)
-g = gp.Covsum(n, 10)
-g.set_data(X, y)
 hp = np.array([np.log(3.0), 0.0, np.log(0.1)])
-for it in range(3):
-    g.set_loghyperparam(hp + 1e-3 * it)
-    print(g.loglik_grad(), flush=True)
-g.close()
+experts = int(os.environ.get("TL_EXPERTS", "0"))
+if experts > 0:
+    b = gp.BCM.split(X, y, experts)
+    for it in range(3):
+        b.set_BCM_log_hyperparam(hp + 1e-3 * it)
+        print(b.loglik_grad()[:2], flush=True)
+    b.close()
+else:
+    g = gp.Covsum(n, 10)
+    g.set_data(X, y)
+    for it in range(3):
+        g.set_loghyperparam(hp + 1e-3 * it)
+        print(g.loglik_grad(), flush=True)
+    g.close()
