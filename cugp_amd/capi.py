@@ -99,6 +99,31 @@ SIGNATURES = {
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """One HIP runtime per process.  The PyTorch-ROCm wheel carries its own libamdhip64 / libhsa-runtime64 (same
+    SONAMEs as /opt/rocm's, an older build): whichever copy a process loads first serves every later user.  With torch
+    imported first libcugp.so simply runs on torch's copy; the other way round torch finds /opt/rocm's runtime under
+    its own libraries' names and fails at the first CUDA call ("No HIP GPUs are available").  So when a torch wheel is
+    installed and not yet imported, its runtime is loaded (not torch itself) before libcugp.so.
+    CUGP_OWN_HIP_RUNTIME=1 keeps the library on the runtime it was linked against."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("CUGP_OWN_HIP_RUNTIME", "0") not in ("", "0"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    rt = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(rt):
+        try:
+            C.CDLL(rt, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass                                    # not loadable here: libcugp.so keeps its own
+
+
 def lib():
     """Load libcugp.so (built in tree by cugp_amd.build); raises if it is not there."""
     global _lib
@@ -106,6 +131,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise FileNotFoundError(
                 "%s not built -- run `python -m cugp_amd.build` (there is no CPU fallback)" % LIB_PATH)
+        _share_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError if the library lacks a declared symbol

@@ -229,12 +229,22 @@ int enqueue_inverse_block(cugp_gp* g, int a, int b, bool kinv, hipStream_t x, hi
 int phase_mark(cugp_gp* g, int i);
 int fetch_eval(cugp_gp* g);
 
+// The shares of K^-1 on a stream of their own (beside the next block's bordering) or behind their block's bordering:
+// for a group of experts two large launches in flight fill each other's partly empty last rounds (-3...-6 % per
+// evaluation at 16x1500, 8x3000, 4x6000); for a single matrix the extra hand-over costs what it gains or more
+// (1500: +1.9 %, 6000: +3.3 %, 8192 / 10000: +-0.3 %, 16384: +0.7 %).  TUNE_LAUUM_STREAM: 0 never, 1 groups, 2 always.
+bool kinv_stream(const cugp_gp* g)
+{
+    const int v = g_tune[TUNE_LAUUM_STREAM];
+    return v >= 2 || (v == 1 && g->grp != nullptr);
+}
+
 int fork_inverse_block(cugp_gp* g, int a, int b, int idx, hipStream_t from)
 {
     HIPCHK(hipEventRecord(g->bev[idx], from));
     HIPCHK(hipStreamWaitEvent(g->aux, g->bev[idx], 0));
     HIPCHK(hipStreamWaitEvent(g->aux2, g->bev[idx], 0));
-    const bool own = g_tune[TUNE_LAUUM_STREAM] != 0;
+    const bool own = kinv_stream(g);
     return enqueue_inverse_block(g, a, b, true, g->aux, g->aux2, g->oev[idx], own ? g->lq : nullptr,
                                  own ? g->lev[idx] : nullptr);
 }
@@ -444,7 +454,7 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false)
     if (w > 0) {
         if ((rc = fork_inverse_block(g, done, nt, nblk, m))) return rc;
         HIPCHK(hipEventRecord(g->bev.back(), g->aux));
-        if (g_tune[TUNE_LAUUM_STREAM] != 0) HIPCHK(hipEventRecord(g->lev.back(), g->lq));
+        if (kinv_stream(g)) HIPCHK(hipEventRecord(g->lev.back(), g->lq));
         g->joined = false;
     } else if (with_inverse) {
         if ((rc = enqueue_inverse_block(g, 0, nt, true, m, nullptr, nullptr))) return rc;
@@ -461,7 +471,7 @@ int join_inverse(cugp_gp* g)
 {
     if (!g->joined) {
         HIPCHK(hipStreamWaitEvent(g->stream, g->bev.back(), 0));
-        if (g_tune[TUNE_LAUUM_STREAM] != 0) HIPCHK(hipStreamWaitEvent(g->stream, g->lev.back(), 0));
+        if (kinv_stream(g)) HIPCHK(hipStreamWaitEvent(g->stream, g->lev.back(), 0));
     }
     g->joined = true;
     return CUGP_OK;

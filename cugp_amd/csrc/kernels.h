@@ -20,7 +20,7 @@ enum { TUNE_LAUUM_WM2_MAX = 0,   // K^-1 product: use 64x64 tiles when there are
        TUNE_NEAR_TILES = 9,      // ... tiles in the near window (updated every step, K = 128) at a panel's first step
        TUNE_WIDE_GRID = 10,      // ... workgroups of the wide update (a bound only matters beside other streams)
        TUNE_PANEL_MIN_NT = 11,   // ... only from this many tiles on (small matrices are bound by the chain alone)
-       TUNE_LAUUM_STREAM = 12,   // the K^-1 share of an inverse block on its own stream beside the next block's bordering (1) or behind it (0)
+       TUNE_LAUUM_STREAM = 12,   // the K^-1 share of an inverse block on its own stream beside the next block's bordering: 0 never, 1 expert groups only, 2 always
        TUNE_STEP_STREAM = 13,    // two-speed step kernel: non-temporal accesses to the C tiles (1) or plain ones (0)
        TUNE_RESERVED_14 = 14,    // (unused)
        TUNE_WIDE_STREAM = 15,    // wide passes on the handle's stream (0) or through a stream of their own (1: another hardware queue, same order)

@@ -772,3 +772,17 @@ def test_results_do_not_depend_on_timing(gp_mod, n):
         seen.append((ll, tuple(gr)))
     assert all(s == seen[0] for s in seen), seen
     g.close()
+
+
+def test_torch_after_the_library_in_one_process():
+    """The PyTorch wheel ships its own HIP runtime under the system runtime's library names: whichever is loaded first
+    serves the whole process.  capi.lib() therefore loads torch's copy when torch is installed but not imported yet
+    (capi._share_torch_hip_runtime); loading libcugp.so FIRST and initialising torch's device afterwards -- the order
+    that used to end in "No HIP GPUs are available" -- must work (own process: this one has imported both already)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "order_probe.py"), "cugp_first"], capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "cugp_first torch ok" in r.stdout

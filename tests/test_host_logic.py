@@ -25,6 +25,23 @@ def test_header_symbols_all_exported_and_bound():
     assert lib.cugp_version() >= 100
 
 
+def test_one_hip_runtime_per_process_whatever_the_import_order():
+    """capi.lib() before `import torch`: the process must end up with ONE libamdhip64 (torch's copy when a torch wheel
+    is installed -- capi._share_torch_hip_runtime), and torch must still import.  Fresh interpreter: this one has
+    imported both long ago."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from cugp_amd import capi\n"
+            "capi.lib()\n"
+            "import torch\n"
+            "libs = sorted(set(l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l))\n"
+            "print('RUNTIMES', len(libs), libs)\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "RUNTIMES 1 " in r.stdout, r.stdout
+
+
 def test_no_device_is_an_error_not_a_fallback():
     """Without a GPU the product path must fail loudly (error code + message), never compute on the CPU."""
     lib = capi.lib()
