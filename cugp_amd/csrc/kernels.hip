@@ -1305,15 +1305,22 @@ __global__ __launch_bounds__(256) void k_trtri_diag(const double* __restrict__ A
     const double* T00 = d64 + (size_t)b * 8192;
     const double* T11 = T00 + 4096;
     {
+        // all 36 loads in flight before the first LDS store (fully unrolled: which of the three sources a micro
+        // tile comes from is then a compile-time choice; as a rolled loop with the branches inside it the loads
+        // went out one at a time and the kernel took 25 us, nearly all of it this prologue)
         const int r = t >> 4, c = t & 15;
+        double v[NLT];
+#pragma unroll
         for (int bi = 0; bi < NMT; bi++)
+#pragma unroll
             for (int bj = 0; bj <= bi; bj++) {
-                double v;
-                if (bi < 4) v = T00[(bi * MT + r) * 64 + bj * MT + c];
-                else if (bj >= 4) v = T11[((bi - 4) * MT + r) * 64 + (bj - 4) * MT + c];
-                else v = Ab[(size_t)(bi * MT + r) * ld + bj * MT + c];            // L10
-                sm[mt_off(bi, bj) + r * (MT + 1) + c] = v;
+                const int q = bi * (bi + 1) / 2 + bj;
+                if (bi < 4) v[q] = T00[(bi * MT + r) * 64 + bj * MT + c];
+                else if (bj >= 4) v[q] = T11[((bi - 4) * MT + r) * 64 + (bj - 4) * MT + c];
+                else v[q] = Ab[(size_t)(bi * MT + r) * ld + bj * MT + c];            // L10
             }
+#pragma unroll
+        for (int q = 0; q < NLT; q++) sm[q * MTS + r * (MT + 1) + c] = v[q];
     }
     __syncthreads();
     {
@@ -1338,6 +1345,7 @@ __global__ __launch_bounds__(256) void k_trtri_diag(const double* __restrict__ A
     __syncthreads();
     double* Tb = T + (size_t)b * TILE * ld + b * TILE;
     double* Ub = U + (size_t)b * TILE * ld + b * TILE;
+#pragma unroll 8
     for (int e = t; e < TILE * TILE; e += 256) {
         const int r = e >> 7, c = e & 127, br = r >> 4, bc = c >> 4;
         // T(r,c) lives in micro tile (br,bc) when bc <= br (diagonal micro tiles are zero above their diagonal)

@@ -779,6 +779,7 @@ def test_torch_after_the_library_in_one_process():
     serves the whole process.  capi.lib() therefore loads torch's copy when torch is installed but not imported yet
     (capi._share_torch_hip_runtime); loading libcugp.so FIRST and initialising torch's device afterwards -- the order
     that used to end in "No HIP GPUs are available" -- must work (own process: this one has imported both already)."""
+    import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
