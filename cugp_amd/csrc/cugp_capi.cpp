@@ -396,6 +396,14 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false)
     // that follows still waits for them: that form only moves them to another hardware queue)
     hipStream_t m = g->stream, wq = g_tune[TUNE_WIDE_STREAM] != 0 ? g->wide : g->stream;
     int nblk = 0, done = 0;                                 // blocks forked so far, block rows handed over
+    // Small matrices: every hand-over costs the main stream a ~11-us bubble (event record + cross-stream wait) and the
+    // chip is mostly idle anyway, so the first nt - 2w block rows go over in ONE block, late, and only the last two
+    // blocks keep the short tail of the fine-grained schedule (-1.5 % at 1000 and 1500 rows; from 2000 rows on the
+    // inverse needs its early start: +8...19 %, hence nt <= 12).
+    // Groups of experts share the launches: with many experts the inverse is throughput work again and wants its early
+    // start (16 x 1500: +4 % when late; 2 x 1500, 5 x 1000: -2...-3 %): at most 64 tile rows over the whole group.
+    const int group_rows = nt * (g->grp ? g->grp->bt.count : 1);
+    const int first = (w > 0 && nt <= g_tune[TUNE_LATE_FORK_NT] && group_rows <= 64 && nt - 2 * w > w) ? nt - 2 * w : w;
     bool wide_used = false;
     g->eval_seq++;
     if (g->grp) HIPCHK(hipMemsetAsync(g->grp->tickets, 0, (size_t)g->grp->bt.count * nt * sizeof(unsigned), m));
@@ -405,7 +413,7 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false)
         launch_trsm_inv64(g->dA, g->d64, ld, kb, nt, m, B(g));
         // block rows < kb+1 of L are final, and so are the columns <= kb of every row below them
         const int b = kb + 1;
-        if (w > 0 && b - done >= w) {
+        if (w > 0 && b - done >= (nblk == 0 ? first : w)) {
             if ((rc = fork_inverse_block(g, done, b, nblk, m))) return rc;
             done = b;
             nblk++;

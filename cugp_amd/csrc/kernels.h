@@ -22,7 +22,7 @@ enum { TUNE_LAUUM_WM2_MAX = 0,   // K^-1 product: use 64x64 tiles when there are
        TUNE_PANEL_MIN_NT = 11,   // ... only from this many tiles on (small matrices are bound by the chain alone)
        TUNE_LAUUM_STREAM = 12,   // the K^-1 share of an inverse block on its own stream beside the next block's bordering: 0 never, 1 expert groups only, 2 always
        TUNE_STEP_STREAM = 13,    // two-speed step kernel: non-temporal accesses to the C tiles (1) or plain ones (0)
-       TUNE_RESERVED_14 = 14,    // (unused)
+       TUNE_LATE_FORK_NT = 14,   // matrices of at most this many tiles hand their first nt - 2w block rows to the inverse streams in ONE block
        TUNE_WIDE_STREAM = 15,    // wide passes on the handle's stream (0) or through a stream of their own (1: another hardware queue, same order)
        TUNE_INVERSE_RESERVE = 16, // compute units the inverse-block streams stay off (CU-masked), so the factorisation's launches always find free slots; 0 = no mask
        TUNE_SPLIT_REM_MAX = 17,  // uniform-K launches (block-wise K^-1 share, bordering, wide update): a last round of at most this many tiles runs as 64x64 quarters
