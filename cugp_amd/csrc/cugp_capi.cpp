@@ -311,6 +311,19 @@ StepPlan plan_step(int nt, int P, int near, int kb)
         sp.wa1 = nt;
     }
     sp.wcol = F - (kb + 1);
+    // Pairs: the near window's tiles cost a fixed ~12 us + 30.5 us per 128 of K each time they are touched, so they
+    // take their updates two steps at a time.  The even step of a pair updates only what the next step's chain
+    // needs -- columns kb+1 (solved next) and kb+2 (whose diagonal block the next launch factors) -- a launch of at
+    // most ~120 tiles that hides behind the diagonal block; the odd step gives every other near column both k tiles
+    // in one pass (la0 / kfirst of the step launch).  Panels are even, so a pair never straddles a wide pass.
+    if (g_tune[TUNE_PAIR_STEPS] != 0 && P % 2 == 0) {
+        if (i % 2 == 0 && kb + 2 < nt) {
+            sp.wcol = 2;                                              // F >= (p+1)P + 1 >= kb + 3: both are near columns
+        } else if (i % 2 == 1) {
+            sp.la0 = kb + 2;
+            sp.kfirst = kb - 1;
+        }
+    }
     return sp;
 }
 

@@ -18,7 +18,7 @@ enum { TUNE_LAUUM_WM2_MAX = 0,   // K^-1 product: use 64x64 tiles when there are
        TUNE_GROUP_MAX_TILES = 7, // experts up to this many tiles share launches (default: all; with the inverse beside the factorisation grouping won at every size tried: 4 x 6000 rows 18.9 -> 18.3 ms, 2 x 8192 rows 23.6 -> 21.9 ms)
        TUNE_PANEL = 8,           // two-speed Cholesky: steps per panel (far columns get K = 128*this in one pass per panel); 1 = classic
        TUNE_NEAR_TILES = 9,      // ... tiles in the near window (updated every step, K = 128) at a panel's first step
-       TUNE_WIDE_GRID = 10,      // ... workgroups of the wide update (a bound only matters beside other streams)
+       TUNE_PAIR_STEPS = 10,     // two-speed form: the near window takes its updates two steps at a time (K = 256), see plan_step
        TUNE_PANEL_MIN_NT = 11,   // ... only from this many tiles on (small matrices are bound by the chain alone)
        TUNE_LAUUM_STREAM = 12,   // the K^-1 share of an inverse block on its own stream beside the next block's bordering: 0 never, 1 expert groups only, 2 always
        TUNE_STEP_STREAM = 13,    // two-speed step kernel: non-temporal accesses to the C tiles (1) or plain ones (0)

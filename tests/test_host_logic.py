@@ -155,6 +155,9 @@ def test_row_partition_matches_reference(oracle, si128):
 # ---------------------------------------------------------------------------------------------
 # two-speed Cholesky: the launch schedule (cugp_potrf_plan = the arithmetic enqueue_potrf uses)
 # ---------------------------------------------------------------------------------------------
+PAIR_STEPS_DEFAULT = 0
+
+
 def _replay_potrf_plan(nt, P, near):
     """Replay the schedule on a set model.  applied[(i, j)] = k tiles subtracted from tile (i, j) so far, in
     launch order (one in-order stream).  Checks that every tile has seen exactly k = 0..j-1, ascending, when its
@@ -170,13 +173,14 @@ def _replay_potrf_plan(nt, P, near):
         for i in range(kb, nt):
             assert applied[(i, kb)] == list(range(kb)), (nt, P, near, kb, i, applied[(i, kb)])
         assert wcol >= 1 and wait == -1 and b1 <= b0
-        far = kb + 1 + wcol                                          # first column outside the near window
-        assert far >= last_far and far <= nt
-        last_far = far
+        far = kb + 1 + wcol                                          # first column outside this launch's window
+        assert far <= nt
         if a1 > a0:
             p = kb // P
             assert (k0, kw) == (p * P, P) and k0 + kw == kb + 1      # the panel just completed ...
             assert (a0, a1) == (far, nt)                             # ... goes to everything beyond the window
+            assert a0 >= last_far                                    # the far boundary never moves backwards
+            last_far = a0
             for j in range(a0, a1):
                 for i in range(j, nt):
                     applied[(i, j)] += list(range(k0, k0 + kw))
@@ -193,10 +197,16 @@ def _replay_potrf_plan(nt, P, near):
 
 
 def test_potrf_plan_covers_every_update_exactly_once_in_order():
-    for P in (1, 2, 3, 4, 5, 8, 16, 32):                 # 16 / 500 is the shipped default
-        for near in (1, 40, 300, 500, 700, 5000):
-            for nt in list(range(2, 30)) + [40, 63, 64, 79]:
-                _replay_potrf_plan(nt, P, near)
+    lib = capi.lib()
+    try:
+        for pairs in (0, 1):                                 # TUNE_PAIR_STEPS: near window updated every / every other step
+            assert lib.cugp_set_tuning(10, pairs) == 0
+            for P in (1, 2, 3, 4, 5, 8, 16, 32):             # 16 / 500 is the shipped default
+                for near in (1, 40, 300, 500, 700, 5000):
+                    for nt in list(range(2, 30)) + [40, 63, 64, 79]:
+                        _replay_potrf_plan(nt, P, near)
+    finally:
+        assert lib.cugp_set_tuning(10, PAIR_STEPS_DEFAULT) == 0
 
 
 def test_cg_sparing_takes_the_default_trajectory_with_fewer_gradients(oracle, si128):
