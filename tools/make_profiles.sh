@@ -24,6 +24,13 @@ for mode in overlap serial; do
   rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_$mode -- python3 $R/tools/timeline_run.py 8192 $pipe > /dev/null 2>&1 || exit 1
   python3 $R/tools/timeline_report.py $(find /tmp/tl_$mode -name '*kernel_trace.csv' | head -1) --launches > $O/${tag}_timeline_${mode}_n8192.txt
 done
+# one 1500-row expert and the 16 x 1500 group (config 5's shape on one GPU)
+for shape in "expert1500 1500 0" "bcm16x1500 24000 16"; do
+  set -- $shape
+  rm -rf /tmp/tl_$1
+  TL_EXPERTS=$3 rocprofv3 --kernel-trace --output-format csv -d /tmp/tl_$1 -- python3 $R/tools/timeline_run.py $2 > /dev/null 2>&1 || exit 1
+  python3 $R/tools/timeline_report.py $(find /tmp/tl_$1 -name '*kernel_trace.csv' | head -1) --launches > $O/${tag}_timeline_$1.txt
+done
 # PMC passes (separate passes; counters only with --kernel-trace)
 for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_LDS_BANK_CONFLICT" "FETCH_SIZE" "WRITE_SIZE"; do
   t=$(echo $pass | cut -d' ' -f1)
