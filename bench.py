@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
+    ap.add_argument("--rehearse-rccl", action="store_true", help="rehearsal on ONE GPU of the code path the ranks of a "
+                    "multi-GPU run take: a 1-rank RCCL process group, the expert's row written into the device tensor and "
+                    "all-reduced there (cugp_bcm_loglik_grad_rows_device)")
     args = ap.parse_args()
 
     import torch
@@ -113,8 +116,10 @@ def main():
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    collective = world > 1 or args.rehearse_rccl
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world,
                                     device_id=torch.device("cuda", local_rank))
@@ -130,7 +135,11 @@ def main():
     for k in range(K):
         if k % world == rank:
             experts[k] = synth(args.n, args.d, 15618 + k)
-    bcm = ShardedBCM(experts, rank=rank, world=world, device=local_rank)
+    bcm = ShardedBCM(experts, rank=rank, world=world, device=local_rank,
+                     comm_device=torch.device("cuda", local_rank) if args.rehearse_rccl else None)
+    if args.rehearse_rccl and world == 1:
+        assert bcm._on_device
+        bcm._allreduce = lambda t: (dist.all_reduce(t, op=dist.ReduceOp.SUM), t)[1]    # the collective, at one rank
     if not bcm.local and strong and K < world:
         pass                                          # more ranks than experts: this rank only takes part in the collectives
     timed_launches = len(bcm.local) == 1              # per-launch HIP events: the single-expert (metric) workload;
@@ -146,7 +155,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -163,7 +172,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-    if world > 1:
+    if collective:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
@@ -278,7 +287,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     bcm.close()
-    if world > 1:
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -68,6 +68,9 @@ class ShardedBCM:
                 else torch.device("cpu")
         self.comm_device = comm_device
         self._rows = torch.zeros((self.K, 4), dtype=torch.float64, device=comm_device)
+        self._send = torch.zeros((self.K, 4), dtype=torch.float64, device=comm_device)
+        if comm_device.type == "cuda":
+            torch.cuda.current_stream(comm_device).synchronize()      # the zeros are there before the library writes rows
         # RCCL path: the per-expert rows go from the evaluation's result buffer straight into this device tensor
         # (no fetch / numpy / H2D on the critical path); needs the library-level BCM of this rank's experts
         self._on_device = (comm_device.type == "cuda" and expert_factory is None and len(self.mine) > 0)
@@ -96,9 +99,11 @@ class ShardedBCM:
     def loglik_grad(self):
         """-> (sum_k LL_k, sum_k grad_k, per-expert LL[K]); one collective of K x 4 doubles."""
         if self._on_device:
-            self._rows.zero_()                    # the other ranks' rows must be exact zeros
-            torch.cuda.current_stream(self.comm_device).synchronize()
-            self._group.loglik_grad_rows_device(self._rows.data_ptr(), self.mine)
+            # _send: zero everywhere except this rank's rows, which every evaluation overwrites (the other ranks' rows
+            # must be exact zeros in the sum); the collective works on a copy, so nothing has to be cleared or waited
+            # for on the host between evaluations
+            self._group.loglik_grad_rows_device(self._send.data_ptr(), self.mine)   # returns with the rows in place
+            self._rows.copy_(self._send)
             out = self._allreduce(self._rows).cpu().numpy()
             return self._ordered_sum(out)
         rows = np.zeros((self.K, 4))

@@ -787,3 +787,21 @@ def test_torch_after_the_library_in_one_process():
                        text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "cugp_first torch ok" in r.stdout
+
+
+def test_bench_multi_rank_code_path_on_one_rank():
+    """bench.py as the ranks of a multi-GPU run execute it -- process group on RCCL, the single local expert behind the
+    library-level BCM, its row written into the device tensor and all-reduced there, per-launch profiling on the
+    borrowed expert handle, max-over-ranks timing -- rehearsed at one rank on the one GPU of this box."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_PORT="29547")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--rehearse-rccl", "--steps", "2", "--warmup", "1",
+                        "--cpu-sample", "0", "--rows", "2048"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and np.isfinite(line["ll_last"])
+    assert line["roofline"]["launches"] >= 0
