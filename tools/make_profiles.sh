@@ -16,6 +16,7 @@ for ov in 1 0; do
 done
 python3 $R/bench.py --rows 1500 --experts-total 16 --cpu-sample 0 > $O/${tag}_bench_bcm16_line.json 2>> $O/bench.err
 python3 $R/bench.py --rows 6000 --experts-total 4 --cpu-sample 0 --steps 10 > $O/${tag}_bench_bcm4_line.json 2>> $O/bench.err
+python3 $R/bench.py --experts-per-gpu 2 --cpu-sample 0 --steps 10 > $O/${tag}_bench_2x8192_line.json 2>> $O/bench.err
 python3 $R/tools/la_bench.py > $O/${tag}_la_bench.txt 2>> $O/bench.err
 python3 $R/tools/bcm_ab.py > $O/${tag}_bcm_one_gpu.txt 2>> $O/bench.err
 for mode in overlap serial; do
