@@ -90,7 +90,7 @@ def main():
                     help="strong-scaling BCM workload: this many experts in total, expert k on rank k mod N "
                          "(e.g. --experts-total 16 --rows 1500 = the si24000 16-shard shape); value = BCM objective "
                          "evaluations/s (all experts + all-reduce per evaluation)")
-    ap.add_argument("--cpu-sample", type=int, default=2048, help="rows for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=2560, help="rows for the CPU baseline (0 = skip)")
     ap.add_argument("--overlap", type=int, default=1, help="0: build the inverse after the factorisation on one stream "
                     "(every kernel has the chip to itself: the per-kernel roofline of the whole run is the isolated one "
                     "and no extra pass is made)")
