@@ -33,6 +33,17 @@ namespace cugp {
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
+// A pointer read out of the experts' table (ExpertPtrs) is a generic pointer to the compiler: every access through it
+// became a FLAT instruction, and flat loads count against lgkmcnt as well as vmcnt -- each wait for an LDS fragment
+// read also waited for the global loads meant to stay in flight behind the MFMAs.  Round-tripping it through the
+// global address space lets the address-space inference make it (and the select with the kernel argument) global.
+template <class T>
+__device__ __forceinline__ T* GP(T* p)
+{
+    // (through an integer: a plain generic -> global -> generic cast pair is folded away before the inference runs)
+    return (T*)(__attribute__((address_space(1))) T*)(unsigned long long)p;
+}
+
 // ------------------------------------------------------------------------------------------
 // fp64 MFMA tile product
 // ------------------------------------------------------------------------------------------
@@ -337,7 +348,7 @@ template <int WM>
 __global__ __launch_bounds__(256, 2) void k_lauum(const double* __restrict__ U, double* __restrict__ Kinv, int ld,
                                                   int a, int w, int nfull, const ExpertPtrs* __restrict__ bt)
 {
-    if (bt) { U = bt[blockIdx.y].U; Kinv = bt[blockIdx.y].Kinv; }
+    if (bt) { U = GP(bt[blockIdx.y].U); Kinv = GP(bt[blockIdx.y].Kinv); }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (WM == 2) {
         lauum_tile<2>(U, Kinv, ld, a, w, blockIdx.x >> 2, blockIdx.x & 3, smem);
@@ -386,7 +397,7 @@ __global__ __launch_bounds__(256, 2) void k_trtri_level(const double* __restrict
                                                         size_t off, const ExpertPtrs* __restrict__ bt)
 {
     // off: element offset of the diagonal sub-matrix the level works on (a block of inverse rows)
-    if (bt) { L = bt[blockIdx.y].A; T = bt[blockIdx.y].T; U = bt[blockIdx.y].U; }
+    if (bt) { L = GP(bt[blockIdx.y].A); T = GP(bt[blockIdx.y].T); U = GP(bt[blockIdx.y].U); }
     L += off; T += off; U += off;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int SUB = 4 / WM;
@@ -431,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void k_trtri_border(const double* __restric
                                                          double* __restrict__ U, int ld, int a, int w, int step,
                                                          int c0, int c1, int nfull, const ExpertPtrs* __restrict__ bt)
 {
-    if (bt) { L = bt[blockIdx.y].A; T = bt[blockIdx.y].T; U = bt[blockIdx.y].U; }
+    if (bt) { L = GP(bt[blockIdx.y].A); T = GP(bt[blockIdx.y].T); U = GP(bt[blockIdx.y].U); }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (WM == 2) {
         border_tile<2>(L, T, U, ld, a, w, step, c0, c1, blockIdx.x >> 2, blockIdx.x & 3, smem);
@@ -493,7 +504,7 @@ __global__ __launch_bounds__(256) void k_mfma_peak(double* sink, int iters)
 __global__ __launch_bounds__(256) void k_trsm_inv64(double* __restrict__ A, const double* __restrict__ d64,
                                                     int ld, int kb, const ExpertPtrs* __restrict__ bt)
 {
-    if (bt) { A = bt[blockIdx.y].A; d64 = bt[blockIdx.y].d64; }
+    if (bt) { A = GP(bt[blockIdx.y].A); d64 = GP(bt[blockIdx.y].d64); }
     __shared__ double xbuf[4][4][64];
     __builtin_amdgcn_s_setprio(3);                      // on the factorisation's serial chain (see k_syrk_step)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -603,7 +614,7 @@ __global__ __launch_bounds__(256) void k_build(const double* __restrict__ X, int
                                                HyperScalars h_arg, const HyperScalars* __restrict__ hd,
                                                double* __restrict__ K, int full, const ExpertPtrs* __restrict__ bt)
 {
-    if (bt) { X = bt[blockIdx.y].X; n = bt[blockIdx.y].n; K = bt[blockIdx.y].A; }
+    if (bt) { X = GP(bt[blockIdx.y].X); n = bt[blockIdx.y].n; K = GP(bt[blockIdx.y].A); }
     const HyperScalars h = hd ? *hd : h_arg;
     __shared__ double xs[KT][DC + 1], ys[KT][DC + 1];
     int ti, tj;
@@ -703,166 +714,246 @@ __device__ __forceinline__ double rsqrt_nr(double x)
     return y;
 }
 
-// Cholesky of one 16x16 micro tile held in LDS (rows padded to 17) together with everything that hangs on it, by
-// up to three waves side by side.  Lane l < 16 of every wave owns row l of the diagonal tile in registers (each wave
-// factors the tile for itself: no hand-over between waves inside the pivot loop), right-looking.  A wave issues
-// one fp64 VALU instruction per ~6.5 cycles, so the pivot loop (the latency floor of the whole factorisation) is
-// written for few instructions and no stalls:
-//   * 1/sqrt(pivot): v_rsq_f64 seed (2^-24) + ONE third-order step y0 (1 + e/2 + 3e^2/8), e = 1 - x y0^2,
-//     folded into the column scaling (error 5/16 e^3 ~ 3e-24: below rounding);
-//   * column c+1 is updated at once with a v_readlane broadcast and gives the next pivot, so the next
-//     1/sqrt chain starts immediately;
-//   * the factors for columns >= c+2 go through a 128-byte LDS buffer and come back as uniform 16-byte
-//     reads; they are applied ONE PIVOT LATER, so the LDS round trip never stalls the chain.
-// Every instruction of that loop runs on all 64 lanes, so lanes 16..63 carry OTHER ROWS through the same
-// elimination for free:
-//   * rows of the column block below the diagonal tile (48 per wave): they come out as x = a L_jj^-T, the forward
-//     substitution that used to be a separate pass of ~3.3k cycles per 16-step;
-//   * one group of 16 lanes (in the first wave with room) starts from the rows of the IDENTITY: row i comes out as
-//     column i of L_jj^-1 -- the 16x16 inverse the 64x64 inverses are built from, which used to cost a
-//     ~5k-cycle substitution per tile.
-// Two calls with a workgroup barrier between them: panel_load (everybody reads the diagonal tile) and
-// panel_factor (the owner's rows go straight to global memory, the inverse replaces the diagonal tile in LDS).
 // workgroup barrier that orders LDS traffic only: global stores in flight are NOT waited for (a __syncthreads
 // would be: ~2k cycles at every barrier once the factored diagonal tiles go straight to global memory)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// ---- panel factor: Cholesky of one 16x16 micro tile held in LDS (rows padded to 17) together with everything that
+// hangs on it, by up to three waves side by side.  Lane l < 16 of every wave owns row l of the diagonal tile in
+// registers (each wave factors the tile for itself: no hand-over between waves inside the pivot loop), right-looking.
+// Every instruction of the loop runs on all 64 lanes, so lanes 16..63 carry OTHER ROWS through the same elimination
+// for free: rows of the column block below the diagonal tile (48 per wave) come out as x = a L_jj^-T, and 16 lanes
+// that start from the rows of the IDENTITY come out as the columns of L_jj^-1.
+// One wave issues an fp64 VALU instruction per ~5.5-6.5 cycles and a dependent one per ~8.3, so the loop -- the
+// latency floor of the whole factorisation -- is written for a short dependent chain and few instructions (round 3;
+// measured by tools/panel_bench.hip: 16 pivots in 2.8k cycles, 175 per pivot; the round-2 loop: 4.2k, 265 per pivot):
+//   * the pivot recurrence is in LDL^T form: the rank-1 update is  r[j] -= (m_i / d) m_j  with the UNSCALED column m,
+//     which is final when the pivot starts -- its trip through LDS (one ds_write, uniform 16-byte reads back by all
+//     64 lanes) starts at once and hides behind the rsq chain (the Cholesky form scales the column by 1/sqrt(d)
+//     first, so that trip started at the END of the chain and its update had to wait a pivot);
+//   * 1/sqrt(d): v_rsq_f64 seed (2^-24) + ONE third-order step y0 (1 + e/2 + 3e^2/8), e = 1 - d y0^2 (error
+//     5/16 e^3 ~ 3e-24: below rounding); the stored factor is x = m y as before, m / d = x y;
+//   * the chain per pivot: rsq, 5 polish ops, x, x y, ONE fma on column c+1, ONE readlane pair for the next pivot
+//     (m_(c+1), the other operand of that fma, came back from LDS a pivot ago);
+//   * software-pipelined by hand (one wave issues in order): the next pivot's v_rsq goes out first, the bulk of the
+//     previous pivot's update (columns >= c+1) fills its latency and the gaps between the polish ops;
+//   * every lane parks its column entry with ONE unmasked ds_write per pivot: rows of the diagonal tile into the
+//     wave's column buffer, passenger rows into dead slots of their own LDS row (element 0, rewritten at the end, and
+//     the pad element 16: the +128-byte immediate that alternates the two column buffers stays inside the 17-double
+//     row), identity rows into parking slots of their own.  Spare lanes repeat rows (same values to the same
+//     addresses) instead of being masked off.
+// Two calls with a workgroup barrier between them: panel_load (everybody reads the diagonal tile) and panel_factor
+// (the owner's rows go straight to global memory, the inverse replaces the diagonal tile in LDS).
 struct PanelLanes {
-    double* myrow;      // LDS row this lane loads from / stores to (rows below), or the diagonal-tile row (lanes < 16)
-    int kind;           // 0 diagonal-tile row, 1 row of the column block below, 2 identity row, 3 idle
-    int idx;            // identity rows: which unit vector
+    double* myrow;      // LDS row this lane loads from (rows of the factor: also where it stores to)
+    double* wslot;      // where the lane parks its column entry at every pivot
+    double* icol;       // identity rows: column `idx` of the diagonal tile in LDS (row stride MT + 1), else unused
+    int kind;           // 0 row of the diagonal tile, 1 row of the column block below, 2 identity row
 };
 
-// IDENT: lanes [inv_lane0, inv_lane0 + 16) carry the identity rows.  (The selects and the extra stores cost
-// ~1.6k cycles per call, more than the inverse is worth on the critical path while other waves have time for the
-// substitution form (micro_inverse): used for the LAST diagonal tile only, whose inverse nothing else could hide.)
-template <bool IDENT>
-__device__ __forceinline__ void panel_load(double* __restrict__ sm, int jb, int nrows, int q0, int inv_lane0,
-                                           PanelLanes& pl, double (&r)[MT])
+// zz: 64 doubles of LDS: [0, 32) a delta vector (1.0 at index 15: identity row i reads its 16 entries from zz + 15 - i,
+// no selects), [32, 64) the parking slots of the identity rows.
+// ident: this wave carries the 16 identity rows in its first spare lanes (the caller picks the wave with >= 16 of them):
+// row i comes out as column i of L_jj^-1 -- the 16x16 inverse the 64x64 inverses are built from -- for free, every
+// instruction of the pivot loop runs on all 64 lanes anyway.  The remaining spare lanes repeat rows (block rows, or the
+// identity rows when the wave holds no block rows): same values to the same addresses.
+__device__ __forceinline__ void panel_load(double* __restrict__ sm, int jb, int nrows, int q0, bool ident,
+                                            double* colbuf, double* zz, PanelLanes& pl, double (&r)[MT])
 {
     const int lane = threadIdx.x & 63;
-    const int q = q0 + lane - MT;                              // my row of the column block (lanes >= 16)
-    pl.kind = lane < MT ? 0 : (q < nrows ? 1 : ((IDENT && lane >= inv_lane0 && lane < inv_lane0 + MT) ? 2 : 3));
-    pl.idx = lane - inv_lane0;
-    // (idle and identity lanes read a row of the diagonal tile: every lane loads unconditionally)
-    pl.myrow = pl.kind == 1 ? sm + mt_off(jb + 1 + (q >> 4), jb) + (q & 15) * (MT + 1)
-                            : sm + mt_off(jb, jb) + (lane & 15) * (MT + 1);
-#pragma unroll
-    for (int c = 0; c < MT; c++) {
-        const double v = pl.myrow[c];
-        r[c] = (IDENT && pl.kind == 2) ? (c == pl.idx ? 1.0 : 0.0) : v;
+    int nv = nrows - q0;                                       // block rows this wave holds: 0, 16, 32 or 48
+    nv = nv < 0 ? 0 : (nv > 48 ? 48 : nv);
+    int l = lane - MT;                                         // lanes >= 16: position among the wave's 48 passenger rows
+    double* diagtile = sm + mt_off(jb, jb);
+    if (lane < MT) {
+        pl.kind = 0;
+        pl.myrow = diagtile + lane * (MT + 1);
+        pl.wslot = colbuf + lane;
+        pl.icol = diagtile;
+    } else {
+        bool isid = ident && l >= nv && l < nv + MT;
+        if (!isid && l >= nv) {                                // spare lane: repeat a block row, or an identity row
+            if (nv > 0) { l -= nv; if (l >= nv) l -= nv; if (l >= nv) l -= nv; }
+            else isid = true;
+        }
+        if (isid) {
+            const int idx = (l - nv) & (MT - 1);
+            pl.kind = 2;
+            pl.myrow = zz + (MT - 1) - idx;
+            pl.wslot = zz + 2 * MT + idx;
+            pl.icol = diagtile + idx;
+        } else {
+            const int q = q0 + l;
+            pl.kind = 1;
+            pl.myrow = sm + mt_off(jb + 1 + (q >> 4), jb) + (q & 15) * (MT + 1);
+            pl.wslot = pl.myrow;
+            pl.icol = diagtile;
+        }
     }
+#pragma unroll
+    for (int c = 0; c < MT; c++) r[c] = pl.myrow[c];
 }
 
-// gdiag (owner wave only, else null): where row 0 of the diagonal tile lives in global memory (row stride ld)
-template <bool IDENT>
-__device__ __forceinline__ void panel_factor(double* __restrict__ sm, int jb, const PanelLanes& pl, double (&r)[MT],
-                                             double* __restrict__ gdiag, int ld, double* __restrict__ rinv,
-                                             double* __restrict__ colbuf)
+__device__ __forceinline__ void panel_factor(const PanelLanes& pl, double (&r)[MT], double* __restrict__ gdiag, int ld,
+                                              double* __restrict__ rinv, const double* colbuf)
 {
+    // (colbuf is written through pl.wslot: no __restrict__)
+    // Software-pipelined by hand, one wave issues in order: the next pivot's v_rsq goes out FIRST, the bulk of the
+    // previous pivot's rank-1 update (columns >= c+1, operands long since back from LDS) fills its latency, then the
+    // polish and the one fma + readlane pair that give the next pivot; as soon as column c+1 is final its LDS trip
+    // and the broadcast of m_(c+2) start.  sched_barriers keep the compiler from sinking the bulk in front of the rsq.
     const int lane = threadIdx.x & 63;
-    const bool diag = lane < MT;
     double piv = readlane_f64(r[0], 0);
-    double myrinv = 0.0;
-    double lprev = 0.0;                       // my factor of the previous pivot column
-    d2 oprev[MT / 2];                         // the previous pivot column (rows of the diagonal tile), read back from LDS
+    double ys[MT];
+    d2 mm[2][MT / 2];                                  // uniform column entries m_j of the pivot in flight / the one before
+    double ltp = 0.0;                                  // -(m / d) of the previous pivot
+    pl.wslot[0] = r[0];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (int c2 = 0; c2 < MT; c2 += 2) mm[0][c2 / 2] = *(const d2*)(colbuf + c2);
+#define CUGP_SB __builtin_amdgcn_sched_barrier(0)
+    // k-th fma of the previous pivot's bulk update (columns c+1 .. 15, column c+1 first: the chain needs it)
+#define CUGP_BULK(k)                                                                                       \
+    do {                                                                                                   \
+        if (c >= 1 && c + 1 + (k) < MT) {                                                                  \
+            const int j_ = c + 1 + (k);                                                                    \
+            r[j_] = __builtin_fma(ltp, mm[(c - 1) & 1][j_ / 2][j_ & 1], r[j_]);                            \
+            CUGP_SB;                                                                                       \
+        }                                                                                                  \
+    } while (0)
 #pragma unroll
     for (int c = 0; c < MT; c++) {
+        const int nb = c >= 1 ? MT - 1 - c : 0;        // fmas of the previous pivot's bulk
+        const int pre = nb > 7 ? nb - 7 : (nb < 3 ? nb : 3);   // in the shadow of the rsq; the rest one per chain op
         const double y0 = __builtin_amdgcn_rsq(piv);
-        const double e = __builtin_fma(-piv * y0, y0, 1.0);
-        const double qq = e * __builtin_fma(e, 0.375, 0.5);
-        // deferred: previous pivot's column applied to columns >= c+1 (column c got it right away)
-        if (c >= 1) {
+        CUGP_SB;
 #pragma unroll
-            for (int c2 = (c + 1) & ~1; c2 < MT; c2 += 2) {
-                if (c2 > c) r[c2] = __builtin_fma(-lprev, oprev[c2 / 2][0], r[c2]);
-                r[c2 + 1] = __builtin_fma(-lprev, oprev[c2 / 2][1], r[c2 + 1]);
-            }
-        }
-        const double ry = r[c] * y0;
-        const double lc = __builtin_fma(ry, qq, ry);
-        r[c] = lc;
-        myrinv = (lane == c) ? __builtin_fma(y0, qq, y0) : myrinv;
+        for (int k = 0; k < pre; k++) CUGP_BULK(k);
+        const double t = -piv * y0;
+        CUGP_SB;
+        CUGP_BULK(pre + 0);
+        const double e = __builtin_fma(t, y0, 1.0);
+        CUGP_SB;
+        CUGP_BULK(pre + 1);
+        const double h = __builtin_fma(e, 0.375, 0.5);
+        CUGP_SB;
+        CUGP_BULK(pre + 2);
+        const double qq = e * h;
+        CUGP_SB;
+        CUGP_BULK(pre + 3);
+        const double y = __builtin_fma(y0, qq, y0);
+        CUGP_SB;
+        CUGP_BULK(pre + 4);
+        const double x = r[c] * y;
+        CUGP_SB;
+        CUGP_BULK(pre + 5);
+        const double lt = -x * y;                      // -(m / d)
+        CUGP_SB;
+        CUGP_BULK(pre + 6);
+        ys[c] = y;
         if (c + 1 < MT) {
-            const double o1 = readlane_f64(lc, c + 1);                 // L[c+1][c] of the diagonal tile
-            r[c + 1] = __builtin_fma(-lc, o1, r[c + 1]);              // column c+1, every row
-            piv = readlane_f64(r[c + 1], c + 1);                      // next pivot
-            if (c + 2 < MT) {
-                double* cb = colbuf + (c & 1) * MT;
-                if (diag) cb[lane] = lc;                              // column c of the diagonal tile
-                // lanes 16..63 read what lanes 0..15 just wrote: tell the compiler (to which a lane that stored
-                // nothing may keep the values it read from this buffer two pivots ago) that LDS has changed;
-                // the hardware executes a wave's LDS operations in order, so no instruction is needed
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            r[c + 1] = __builtin_fma(lt, mm[c & 1][(c + 1) / 2][(c + 1) & 1], r[c + 1]);   // m_(c+1): back from LDS a pivot ago
+            CUGP_SB;
+            piv = readlane_f64(r[c + 1], c + 1);       // next pivot
+            pl.wslot[((c + 1) & 1) * MT] = r[c + 1];   // column c+1 is final: on its way
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
-                for (int c2 = (c + 2) & ~1; c2 < MT; c2 += 2) oprev[c2 / 2] = *(const d2*)(cb + c2);
-                lprev = lc;
-            }
+            for (int c2 = (c + 2) & ~1; c2 < MT; c2 += 2) mm[(c + 1) & 1][c2 / 2] = *(const d2*)(colbuf + ((c + 1) & 1) * MT + c2);
         }
+        r[c] = x;
+        ltp = lt;
+        CUGP_SB;
     }
-    if (pl.kind == 0) {
-        if (gdiag) {                                                  // the factor's diagonal tile: final, to global
-            rinv[lane] = myrinv;
-            double* g = gdiag + (size_t)lane * ld;
-#pragma unroll
-            for (int c = 0; c < MT; c += 2) *(d2*)(g + c) = (d2){c <= lane ? r[c] : 0.0, c + 1 <= lane ? r[c + 1] : 0.0};
-            if (!IDENT) {                                             // ... and to LDS for micro_inverse_inplace
-#pragma unroll
-                for (int c = 0; c < MT; c++) pl.myrow[c] = r[c];      // (entries above the diagonal are never read)
-            }
-        }
-    } else if (pl.kind == 1) {
+#undef CUGP_BULK
+#undef CUGP_SB
+    if (pl.kind == 1) {
 #pragma unroll
         for (int c = 0; c < MT; c++) pl.myrow[c] = r[c];
-    } else if (IDENT && pl.kind == 2) {
-        // my row is column idx of L_jj^-1: the inverse replaces the diagonal tile in LDS (nobody reads L_jj there
-        // any more: the other waves took their copy before the barrier, the factor itself went to global memory)
-        double* tile = sm + mt_off(jb, jb);
+    } else if (pl.kind == 2) {
+        // my row is column idx of L_jj^-1: the inverse replaces the diagonal tile in LDS (every factoring wave took its
+        // copy of the tile before the barrier in front of this call; the factor itself goes to global memory below)
 #pragma unroll
-        for (int c = 0; c < MT; c++) tile[c * (MT + 1) + pl.idx] = r[c];
+        for (int c = 0; c < MT; c++) pl.icol[c * (MT + 1)] = r[c];
+    } else if (gdiag) {                                                  // the owner wave: the factor's diagonal tile is final
+        double* g = gdiag + (size_t)lane * ld;
+        // (entries above the diagonal of a diagonal micro tile are never read on the device, and cugp_get_cholesky
+        //  zeroes the strict upper triangle on the host: no masking)
+#pragma unroll
+        for (int c = 0; c < MT; c += 2) *(d2*)(g + c) = (d2){r[c], r[c + 1]};
+        if (lane == 0) {
+#pragma unroll
+            for (int c = 0; c < MT; c += 2) *(d2*)(rinv + c) = (d2){ys[c], ys[c + 1]};
+        }
     }
 }
 
-// inverse of one factored 16x16 micro tile IN PLACE in LDS: lane j builds column j of L^-1 by forward substitution,
-// column by column of L (right-looking: the dependent chain is t_k -> t_(k+1), the 120 updates in between are
-// independent).  The factor itself is already in global memory (panel_factor), nobody reads it from LDS any more.
-__device__ __forceinline__ void micro_inverse_inplace(double* __restrict__ tile, const double* __restrict__ rinv)
-{
-    const int lane = threadIdx.x & 63, j = lane & 15;
-    double tc[MT];
-#pragma unroll
-    for (int i = 0; i < MT; i++) tc[i] = (i == j) ? 1.0 : 0.0;
-#pragma unroll
-    for (int k = 0; k < MT; k++) {
-        tc[k] *= rinv[k];
-#pragma unroll
-        for (int i = k + 1; i < MT; i++) tc[i] = __builtin_fma(-tile[i * (MT + 1) + k], tc[k], tc[i]);
-    }
-    if (lane < MT) {
-#pragma unroll
-        for (int i = 0; i < MT; i++) tile[i * (MT + 1) + j] = tc[i];
-    }
-}
-
-// C(bi,bj) -= X(bi,jb) * X(bj,jb)^T on LDS micro tiles, one wave, 4 MFMAs
-__device__ __forceinline__ void micro_update(double* __restrict__ sm, int bi, int bj, int jb)
+// C(bi,bj) -= sum_{p in [p0, p1)} X(bi,p) X(bj,p)^T on LDS micro tiles, one wave, NT tiles (bi, bi+1, .. of one
+// column) side by side: every finished panel the tiles still lack in ONE pass over them (4 MFMAs per tile and panel,
+// two accumulation chains each; the next panel's operands are requested before the current one's MFMAs, whose issue
+// time (~550 cycles per tile from one wave) covers the LDS latency).  A tile alone pays ~400 cycles of prologue and
+// epilogue (operand latency, the wait for its last MFMA before the store); two side by side share them -- the first
+// tile's sums and stores issue while the second's MFMAs are still in flight.
+template <int NT, int NP>   // NP = p1 - p0 panels, unrolled (as a rolled loop the compiler carried the accumulators in
+                            // VGPRs and copied all of them to the MFMA's AGPRs and back on every trip)
+__device__ __forceinline__ void micro_update_np(double* __restrict__ sm, int bi, int bj, int p0)
 {
     const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-    double* C = sm + mt_off(bi, bj);
-    const double* Xi = sm + mt_off(bi, jb);
-    const double* Xj = sm + mt_off(bj, jb);
-    d4 acc, acc2 = (d4){0.0, 0.0, 0.0, 0.0};            // two independent chains (dependent MFMAs issue at half rate)
+    double* C[NT];
+    const double* Xi[NT];
+    const double* Xj = sm + mt_off(bj, p0) + c * (MT + 1) + g;          // tiles (b, p), (b, p+1) are MTS doubles apart
+    d4 acc[NT], acc2[NT];
+    double a[NP][NT][4], b[NP][4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) acc[r] = C[(g + 4 * r) * (MT + 1) + c];
+    for (int s = 0; s < 4; s++) b[0][s] = Xj[4 * s];
 #pragma unroll
-    for (int s = 0; s < 4; s += 2) {
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xi[c * (MT + 1) + 4 * s + g], Xj[c * (MT + 1) + 4 * s + g], acc, 0,
-                                                   0, 0);
-        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(-Xi[c * (MT + 1) + 4 * (s + 1) + g],
-                                                    Xj[c * (MT + 1) + 4 * (s + 1) + g], acc2, 0, 0, 0);
+    for (int n = 0; n < NT; n++) {
+        C[n] = sm + mt_off(bi + n, bj);
+        Xi[n] = sm + mt_off(bi + n, p0) + c * (MT + 1) + g;
+#pragma unroll
+        for (int s = 0; s < 4; s++) a[0][n][s] = -Xi[n][4 * s];
+#pragma unroll
+        for (int r = 0; r < 4; r++) acc[n][r] = C[n][(g + 4 * r) * (MT + 1) + c];
+        acc2[n] = (d4){0.0, 0.0, 0.0, 0.0};
     }
 #pragma unroll
-    for (int r = 0; r < 4; r++) C[(g + 4 * r) * (MT + 1) + c] = acc[r] + acc2[r];
+    for (int p = 0; p < NP; p++) {
+        if (p + 1 < NP) {                                                // next panel's operands on their way
+#pragma unroll
+            for (int s = 0; s < 4; s++) b[p + 1][s] = Xj[(p + 1) * MTS + 4 * s];
+#pragma unroll
+            for (int n = 0; n < NT; n++)
+#pragma unroll
+                for (int s = 0; s < 4; s++) a[p + 1][n][s] = -Xi[n][(p + 1) * MTS + 4 * s];
+        }
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+            acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[p][n][0], b[p][0], acc[n], 0, 0, 0);
+            acc2[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[p][n][1], b[p][1], acc2[n], 0, 0, 0);
+        }
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+            acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[p][n][2], b[p][2], acc[n], 0, 0, 0);
+            acc2[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[p][n][3], b[p][3], acc2[n], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < NT; n++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) C[n][(g + 4 * r) * (MT + 1) + c] = acc[n][r] + acc2[n][r];
+}
+
+template <int NT>
+__device__ __forceinline__ void micro_update_multi(double* __restrict__ sm, int bi, int bj, int p0, int p1)
+{
+    switch (p1 - p0) {
+    case 1: micro_update_np<NT, 1>(sm, bi, bj, p0); break;
+    case 2: micro_update_np<NT, 2>(sm, bi, bj, p0); break;
+    case 3: micro_update_np<NT, 3>(sm, bi, bj, p0); break;
+    case 4: micro_update_np<NT, 4>(sm, bi, bj, p0); break;
+    case 5: micro_update_np<NT, 5>(sm, bi, bj, p0); break;
+    case 6: micro_update_np<NT, 6>(sm, bi, bj, p0); break;
+    default: break;
+    }
 }
 
 // The same for NB tiles at once (tile n of the step = the n-th of (bj = jb+1.., bi = bj..7) in that order): all
@@ -942,7 +1033,15 @@ __device__ __forceinline__ void micro_update_run(double* __restrict__ sm, int jb
 // the inverse), and this block's share of log|K|.
 // ------------------------------------------------------------------------------------------
 #ifdef CUGP_STAMPS   // diagnostic build only (tools/chain_bench.hip): cycle stamps of wave 0 into a side buffer
-__device__ unsigned long long g_stamps[64];
+__device__ unsigned long long g_stamps[128];
+#define WSTAMP(i)                                                                  \
+    do {                                                                           \
+        if ((threadIdx.x & 63) == 0) {                                             \
+            unsigned long long t_;                                                 \
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+            g_stamps[i] = t_;                                                      \
+        }                                                                          \
+    } while (0)
 #define STAMP(i)                                                                   \
     do {                                                                           \
         if (threadIdx.x == 0) {                                                    \
@@ -953,6 +1052,7 @@ __device__ unsigned long long g_stamps[64];
     } while (0)
 #else
 #define STAMP(i)
+#define WSTAMP(i)
 #endif
 
 // one MFMA 16x16x16 product on LDS micro tiles, "NN": acc += A(tile a)[row][k] * B(tile b)[k][col]
@@ -984,79 +1084,92 @@ __device__ __forceinline__ void micro_store(double* __restrict__ tile, d4 v)
     for (int r = 0; r < 4; r++) tile[(g + 4 * r) * (MT + 1) + c] = v[r];
 }
 
+// Which finished panels the helper waves (the ones not factoring) bring into which micro tiles while panel q is being
+// factored.  Column q+1 gets ALL panels older than q in one pass over its tiles, one phase before it is needed (panel q
+// itself follows in U1, by every wave, as soon as it exists): 4q MFMAs per tile, at most 24 per helper wave -- the
+// ~3.3k cycles one wave needs to issue them fit under the ~3.5k cycles of the 16 pivots, in every phase.  (The
+// right-looking order this replaces gave the two helper waves of the first phases 21 and 15 tiles: 9k and 7k cycles.)
+// Two range tasks per (phase, helper): rows [bi0, bi1] of column bj take panels [p0, p1); 15 bits each.
+__device__ __forceinline__ unsigned helper_tasks(int q, int h)
+{
+#define CUGP_T(bi0, bi1, bj, p0, p1) ((unsigned)((bi0) | (bi1) << 3 | (bj) << 6 | (p0) << 9 | (p1) << 12))
+    switch (q * 4 + h) {
+    case 1 * 4 + 0: return CUGP_T(2, 7, 2, 0, 1);                                      // 24 MFMAs (the only helper)
+    case 2 * 4 + 0: return CUGP_T(3, 5, 3, 0, 2);                                      // 24
+    case 2 * 4 + 1: return CUGP_T(6, 7, 3, 0, 2) | CUGP_T(7, 7, 5, 0, 2) << 16;        // 16 + 8 (ahead of phase 4)
+    case 3 * 4 + 0: return CUGP_T(4, 5, 4, 0, 3);                                      // 24
+    case 3 * 4 + 1: return CUGP_T(6, 7, 4, 0, 3);                                      // 24
+    case 4 * 4 + 0: return CUGP_T(5, 5, 5, 0, 4) | CUGP_T(7, 7, 5, 2, 4) << 16;        // 16 + 8
+    case 4 * 4 + 1: return CUGP_T(6, 6, 5, 0, 4);                                      // 16
+    case 5 * 4 + 0: return CUGP_T(6, 6, 6, 0, 5);                                      // 20
+    case 5 * 4 + 1: return CUGP_T(7, 7, 6, 0, 5);                                      // 20
+    case 6 * 4 + 0: return CUGP_T(7, 7, 7, 0, 6);                                      // 24
+    default: return 0u;
+    }
+#undef CUGP_T
+}
+
 __device__ __forceinline__ void potf2_body(double* __restrict__ Ab, int ld, double* __restrict__ d16blk,
                                            double* __restrict__ d64blk, double* __restrict__ logdet_out,
                                            double* __restrict__ sm, double* __restrict__ red)
 {
     double* rinv = sm + NLT * MTS;                          // 1 / L_ii, 128 entries
-    double* colbuf = red;                                   // pivot columns: 2 x 16 doubles for each of 3 waves
-    (void)d16blk;                                           // (16x16 inverses now live in LDS only)
+    double* colbuf = red;                                   // pivot columns: 2 x 16 doubles for each of the 4 waves
+    double* zz = red + TILE;                                // delta vector + parking slots of the identity rows (panel_load)
+    (void)d16blk;                                           // (16x16 inverses live in LDS only)
     // (the wave index through readfirstlane: the compiler then knows that everything decided by it -- which tiles
     //  a wave updates, which rows it factors -- is wave-uniform and keeps that control flow on the scalar unit)
     const int t = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(t >> 6);
     __builtin_amdgcn_s_setprio(3);                          // this workgroup is the critical path of the step
 
     STAMP(0);
-    {   // load the lower micro tiles; thread t = element (t>>4, t&15) of every tile
+    {   // load the lower micro tiles; thread t = element (t>>4, t&15) of every tile.  All 36 loads in flight before
+        // the first LDS store (fully unrolled; as a rolled loop they went out a few at a time: 3.9k cycles)
         const int r = t >> 4, c = t & 15;
+        double v[NLT];
+#pragma unroll
         for (int bi = 0; bi < NMT; bi++)
-            for (int bj = 0; bj <= bi; bj++)
-                sm[mt_off(bi, bj) + r * (MT + 1) + c] = Ab[(size_t)(bi * MT + r) * ld + bj * MT + c];
+#pragma unroll
+            for (int bj = 0; bj <= bi; bj++) v[bi * (bi + 1) / 2 + bj] = Ab[(size_t)(bi * MT + r) * ld + bj * MT + c];
+#pragma unroll
+        for (int q = 0; q < NLT; q++) sm[q * MTS + r * (MT + 1) + c] = v[q];
+        if (t < 2 * MT) zz[t] = t == MT - 1 ? 1.0 : 0.0;
     }
     __syncthreads();
     STAMP(1);
-    // Step jb = (P) panel factor of micro-tile column jb: diagonal tile, the rows below it (48 per wave) and the
-    // identity rows that become its 16x16 inverse (panel_load / panel_factor); (U) rank-16 update of the trailing
-    // micro tiles.  Look-ahead: the update first brings column jb+1 up to date (U1, all waves), then the waves
-    // that hold rows of column jb+1 factor it (P of the next step) while the others finish the update (U2).
-    // rows below diagonal tile s: 16 * (7 - s).  Waves 0 .. rows/48 run P: wave rows/48 holds the last rows%48 rows
-    // and, behind them, the identity rows.
+    // Phase q = 0..7:  P(q) panel factor of micro-tile column q -- the diagonal tile, the rows below it (48 per wave)
+    // and 16 identity rows that come out as the tile's 16x16 inverse (panel_load / panel_factor) -- by waves 0..iw,
+    // iw = rows / 48: the last of them is the one with >= 16 spare lanes (or holds the identity rows alone).  Beside
+    // it the other waves run H(q): the older panels into column q+1 (helper_tasks).  Then U1(q), every wave: panel q
+    // into column q+1, and on to P(q+1).
     // (barriers in this loop order LDS traffic only -- lds_barrier: the diagonal tiles' global stores drain behind them)
     PanelLanes pl;
     double pr[MT];
     double* gblk = Ab;                                       // global home of the 128x128 block (row stride ld)
-    {
-        const int rows = (NMT - 1) * MT, wlast = rows / 48;
-        if (wave <= wlast) panel_load<false>(sm, 0, rows, wave * 48, -1, pl, pr);
-        lds_barrier();
-        if (wave <= wlast) panel_factor<false>(sm, 0, pl, pr, wave == 0 ? gblk : nullptr, ld, rinv, colbuf + wave * 2 * MT);
-    }
-    lds_barrier();
-    STAMP(2);
-    for (int jb = 0; jb < NMT - 1; jb++) {
-        const int m = NMT - 1 - jb;                         // micro tiles per edge of the trailing part
-        const int ntiles = m * (m + 1) / 2;
-        micro_update_run(sm, jb, wave, 4, m);               // U1: column jb+1 = tiles 0 .. m-1
-        lds_barrier();
-        STAMP(3 + 3 * jb);
-        const int s1 = jb + 1, rows = (m - 1) * MT, np = rows > 48 ? 2 : 1;
-        // U2 = tiles m .. ntiles-1.  The first steps have more of them (21, 15) than two waves finish while the
-        // other two factor: the factoring waves take the last `ap` tiles each when they are done
-        const int ap = jb == 0 ? 2 : (jb == 1 ? 1 : 0);
-        const int nfree = ntiles - np * ap;
-        const bool last = s1 == NMT - 1;                    // no rows below: lanes 16..31 of wave 0 take the identity
-        if (wave < np) {
-            if (last) panel_load<true>(sm, s1, rows, wave * 48, MT, pl, pr);
-            else panel_load<false>(sm, s1, rows, wave * 48, -1, pl, pr);
-        }
+    for (int q = 0; q < NMT; q++) {
+        const int rows = (NMT - 1 - q) * MT, iw = rows / 48;
+        if (wave <= iw) panel_load(sm, q, rows, wave * 48, wave == iw, colbuf + wave * 2 * MT, zz, pl, pr);
         lds_barrier();                                      // every factoring wave has its copy of the diagonal tile
-        if (wave < np) {
-            double* gd = wave == 0 ? gblk + (size_t)s1 * MT * ld + s1 * MT : nullptr;
-            if (last) panel_factor<true>(sm, s1, pl, pr, gd, ld, rinv + s1 * MT, colbuf + wave * 2 * MT);
-            else panel_factor<false>(sm, s1, pl, pr, gd, ld, rinv + s1 * MT, colbuf + wave * 2 * MT);
-            if (ap > 0) micro_update_run(sm, jb, nfree + wave, np, ntiles);
+        if (wave <= iw) {
+            double* gd = wave == 0 ? gblk + (size_t)q * MT * ld + q * MT : nullptr;
+            panel_factor(pl, pr, gd, ld, rinv + q * MT, colbuf + wave * 2 * MT);
         } else {
-            micro_update_run(sm, jb, m + (wave - np), 4 - np, nfree);       // U2: the other columns
-            // 16x16 inverses of finished diagonal tiles (in place in LDS) while the last, small panels are
-            // factored: tiles 0, 1, 2 at s1 = 4; 3, 4 at s1 = 5; 5 at s1 = 6; 6 at s1 = 7 (7: identity lanes above)
-            int qi = -1;
-            if (s1 == 4) qi = wave - 1;
-            else if (s1 == 5) qi = wave <= 2 ? 2 + wave : -1;
-            else if (s1 >= 6 && wave == 1) qi = s1 - 1;
-            if (qi >= 0) micro_inverse_inplace(sm + mt_off(qi, qi), rinv + qi * MT);
+            unsigned code = helper_tasks(q, wave - iw - 1);
+            for (; code & 0x7fffu; code >>= 16) {
+                const int bi1 = code >> 3 & 7, bj = code >> 6 & 7, p0 = code >> 9 & 7, p1 = code >> 12 & 7;
+                int bi = code & 7;
+                for (; bi + 1 <= bi1; bi += 2) micro_update_multi<2>(sm, bi, bj, p0, p1);
+                if (bi <= bi1) micro_update_multi<1>(sm, bi, bj, p0, p1);
+            }
         }
+        WSTAMP(64 + q * 4 + wave);                         // (diagnostic build: when each wave reaches the barrier)
         lds_barrier();
-        STAMP(4 + 3 * jb);
+        STAMP(2 + 2 * q);
+        if (q + 1 < NMT) {
+            micro_update_run(sm, q, wave, 4, NMT - 1 - q);  // U1: column q+1 = tiles 0 .. m-1 of panel q's update
+            lds_barrier();
+        }
+        STAMP(3 + 2 * q);
     }
 
     STAMP(30);
@@ -1122,9 +1235,9 @@ __global__ __launch_bounds__(256) void k_potf2(double* __restrict__ A, int ld, i
                                                double* __restrict__ d64, double* __restrict__ logdet_part,
                                                const ExpertPtrs* __restrict__ bt)
 {
-    if (bt) { A = bt[blockIdx.y].A; d16 = bt[blockIdx.y].d16; d64 = bt[blockIdx.y].d64; logdet_part = bt[blockIdx.y].logdet; }
+    if (bt) { A = GP(bt[blockIdx.y].A); d16 = GP(bt[blockIdx.y].d16); d64 = GP(bt[blockIdx.y].d64); logdet_part = GP(bt[blockIdx.y].logdet); }
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    __shared__ double red[TILE];
+    __shared__ double red[TILE + 4 * MT];
     potf2_body(A + (size_t)kb * TILE * ld + kb * TILE, ld, d16 + (size_t)kb * NMT * (MT * MT),
                d64 + (size_t)kb * 8192, logdet_part + kb, sm, red);
 }
@@ -1188,10 +1301,10 @@ __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, in
     const int bid = bt ? blockIdx.y : blockIdx.x;
     if (bt) {
         const ExpertPtrs& e = bt[blockIdx.x];
-        A = e.A; d16 = e.d16; d64 = e.d64; logdet_part = e.logdet; tickets = e.tickets;
+        A = GP(e.A); d16 = GP(e.d16); d64 = GP(e.d64); logdet_part = GP(e.logdet); tickets = GP(e.tickets);
     }
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    __shared__ double red[TILE];
+    __shared__ double red[TILE + 4 * MT];
     __shared__ unsigned s_ticket;
     if (bid < NDIAGWG) {
         // the factorisation's serial chain: win instruction issue over the product waves sharing the SIMD
@@ -1260,7 +1373,7 @@ __global__ __launch_bounds__(256, 2) void k_syrk_wide(double* __restrict__ A, in
                                                       int cb, int ntiles, int nfull, int rev,
                                                       const ExpertPtrs* __restrict__ bt)
 {
-    if (bt) A = bt[blockIdx.y].A;
+    if (bt) A = GP(bt[blockIdx.y].A);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __builtin_amdgcn_s_setprio(1);
     if ((int)blockIdx.x >= nfull) {
@@ -1297,7 +1410,7 @@ __global__ __launch_bounds__(256) void k_trtri_diag(const double* __restrict__ A
                                                     const double* __restrict__ d64, double* __restrict__ T,
                                                     double* __restrict__ U, const ExpertPtrs* __restrict__ bt)
 {
-    if (bt) { A = bt[blockIdx.y].A; d64 = bt[blockIdx.y].d64; T = bt[blockIdx.y].T; U = bt[blockIdx.y].U; }
+    if (bt) { A = GP(bt[blockIdx.y].A); d64 = GP(bt[blockIdx.y].d64); T = GP(bt[blockIdx.y].T); U = GP(bt[blockIdx.y].U); }
     extern __shared__ __attribute__((aligned(16))) double sm[];       // 36 lower micro tiles, as potf2_body
     const int t = threadIdx.x, wave = t >> 6;
     const int b = kb + blockIdx.x;
@@ -1369,7 +1482,7 @@ __global__ __launch_bounds__(256) void k_trmv_lower(const double* __restrict__ T
                                                     const double* __restrict__ x, double* __restrict__ z,
                                                     const ExpertPtrs* __restrict__ bt)
 {
-    if (bt) { T = bt[blockIdx.y].T; x = bt[blockIdx.y].y; z = bt[blockIdx.y].z; }
+    if (bt) { T = GP(bt[blockIdx.y].T); x = GP(bt[blockIdx.y].y); z = GP(bt[blockIdx.y].z); }
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= npad) return;
     const int kend = (row / TILE + 1) * TILE;
@@ -1388,7 +1501,7 @@ __global__ __launch_bounds__(256) void k_trmv_upper(const double* __restrict__ U
                                                     const double* __restrict__ x, double* __restrict__ a,
                                                     const ExpertPtrs* __restrict__ bt)
 {
-    if (bt) { U = bt[blockIdx.y].U; x = bt[blockIdx.y].z; a = bt[blockIdx.y].alpha; }
+    if (bt) { U = GP(bt[blockIdx.y].U); x = GP(bt[blockIdx.y].z); a = GP(bt[blockIdx.y].alpha); }
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= npad) return;
     const int kbeg = (row / TILE) * TILE;
@@ -1406,7 +1519,7 @@ __global__ __launch_bounds__(256) void k_trmv_upper(const double* __restrict__ U
 __global__ __launch_bounds__(256) void k_copy_y_to_w(int npad, const ExpertPtrs* __restrict__ bt)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < npad) bt[blockIdx.y].w[i] = bt[blockIdx.y].y[i];
+    if (i < npad) GP(bt[blockIdx.y].w)[i] = GP(bt[blockIdx.y].y)[i];
 }
 
 // blocked forward substitution L z = y (LL-only path): step kb = (1) z_kb = T_kk w_kb, (2) w[rows below] -= L21 z_kb
@@ -1414,7 +1527,7 @@ __global__ __launch_bounds__(256) void k_trsv_diag(const double* __restrict__ T,
                                                    const double* __restrict__ w, double* __restrict__ z,
                                                    const ExpertPtrs* __restrict__ bt)
 {
-    if (bt) { T = bt[blockIdx.y].T; w = bt[blockIdx.y].w; z = bt[blockIdx.y].z; }
+    if (bt) { T = GP(bt[blockIdx.y].T); w = GP(bt[blockIdx.y].w); z = GP(bt[blockIdx.y].z); }
     // z_kb = T_kk w_kb (128x128, lower): two threads per row, 64 columns each, 16-byte loads
     __shared__ double ws[TILE];
     const int k0 = kb * TILE, t = threadIdx.x;
@@ -1438,7 +1551,7 @@ __global__ __launch_bounds__(256) void k_trsv_update(const double* __restrict__ 
                                                      const double* __restrict__ z, double* __restrict__ w,
                                                      const ExpertPtrs* __restrict__ bt)
 {
-    if (bt) { A = bt[blockIdx.y].A; z = bt[blockIdx.y].z; w = bt[blockIdx.y].w; }
+    if (bt) { A = GP(bt[blockIdx.y].A); z = GP(bt[blockIdx.y].z); w = GP(bt[blockIdx.y].w); }
     const int k0 = kb * TILE;
     const int row = k0 + TILE + blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= npad) return;
@@ -1457,7 +1570,7 @@ __global__ __launch_bounds__(256) void k_trace(const double* __restrict__ X, int
 {
     if (bt) {
         const ExpertPtrs& e = bt[blockIdx.y];
-        X = e.X; n = e.n; Kinv = e.Kinv; alpha = e.alpha; part = e.part;
+        X = GP(e.X); n = e.n; Kinv = GP(e.Kinv); alpha = GP(e.alpha); part = GP(e.part);
     }
     const HyperScalars h = hd ? *hd : h_arg;
     __shared__ double xs[KT][DC + 1], ys[KT][DC + 1];
@@ -1515,8 +1628,8 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ z, 
 {
     if (bt) {
         const ExpertPtrs& e = bt[blockIdx.y];
-        z = e.z; n = e.n; logdet_part = e.logdet; out = e.out;
-        if (part) part = e.part;
+        z = GP(e.z); n = e.n; logdet_part = GP(e.logdet); out = GP(e.out);
+        if (part) part = GP(e.part);
     }
     const HyperScalars h = hd ? *hd : h_arg;
     __shared__ double red[5][256];

@@ -196,6 +196,8 @@ def big(r, n):
 SC = os.path.join(REF, "scaling_dataset")
 HP_TWO = [2.0, 2.0, 2.0]                          # cuda_scalingdist/main.cpp:298-301
 R2 = os.path.join(HERE, "golden_r2")
+HP_TAIL = [0.882908, 0.098703, -2.971479]         # cuda_bettersinglenode_ver2/REF:3167,3183 (end of the CG run)
+HP_ILL = [3.762111, 0.098703, -2.971479]          # HP_DENSE's length scale, the tail's amplitude and noise
 
 
 def make_data():
@@ -253,6 +255,40 @@ def job(r, name):
             out["cases"].append({"hp": hp, "ll": ll, "ll_per_expert_6dp": per, "grad": g.tolist(), "Xt": Xt.tolist(),
                                  "yt": yt.tolist(), "pred_mean": m.tolist(), "pred_var": v.tolist(),
                                  "nlpp": b.nlpp(yt, m, v)})
+    elif name in ("si24000_bcm16_tail",):
+        # round 3: config 5 at the hyper-parameters the reference's CG ends at (REF:3167-3183)
+        X, y = _rows("si24000")
+        b = r.bcm(X, y, 16, HP_TAIL)
+        log = os.path.join(tempfile.mkdtemp(), "ll.log")
+        ll = b.loglik(log)
+        per = [float(m.group(1)) for m in re.finditer(r"LL of Expert \d+: ([-\d.]+)", open(log).read())]
+        out = {"K": 16, "rows": [0, 24000], "hp": HP_TAIL, "ll": ll, "ll_per_expert_6dp": per,
+               "grad": b.grad().tolist()}
+    elif name == "cg_sine1024":
+        # round 3: a cg_solve trajectory above 256 rows (covkernel.cpp:405-647)
+        d = np.load(os.path.join(HERE, "data_sine_4160.npz"))
+        X, y = d["X"][:1024], d["y"][:1024]
+        log = os.path.join(tempfile.mkdtemp(), "cg.log")
+        final = r.cg_solve(X, y, HP_DENSE, log)
+        out = {"rows": "sine_1024", "n": 1024, "hp0": HP_DENSE, "final_hp": final.tolist(),
+               "final_ll": r.loglik(X, y, final), "please_see": parse_please_see(log)}
+    elif re.match(r"(tail|ill)(\d+)_(ll|grad)$", name):
+        # round 3: the ill-conditioned regime.  "tail" = REF's end point on sine rows; "ill" = the dense
+        # length scale of HP_DENSE with the tail's amplitude and noise (cond(K) ~ n*sf2/sn2)
+        m = re.match(r"(tail|ill)(\d+)_(ll|grad)$", name)
+        n = int(m.group(2))
+        d = np.load(os.path.join(HERE, "data_sine_4160.npz"))
+        X, y = d["X"][:n], d["y"][:n]
+        hp = HP_TAIL if m.group(1) == "tail" else HP_ILL
+        out = {"rows": "sine_%d" % n, "n": n, "hp": hp}
+        if m.group(3) == "ll":
+            out["ll"] = r.loglik(X, y, hp)
+            if n <= 4096:
+                K = r.K_train(X, hp)
+                w = np.linalg.eigvalsh(K)
+                out["cond_K"] = float(w[-1] / w[0])
+        else:
+            out["grad"] = r.grad(X, y, hp).tolist()
     else:
         m = re.match(r"(d8192|s10000|si6000_\d)_(ll|grad)(_two)?$", name)
         if not m:
@@ -272,6 +308,8 @@ def job(r, name):
 
 JOBS = (["s10000_grad", "d8192_grad", "s10000_ll"] + ["si6000_%d_grad" % k for k in range(4)] + ["d8192_ll"]
         + ["si6000_%d_ll" % k for k in range(4)] + ["si24000_bcm16"])      # longest first
+JOBS_R3 = ["tail4096_grad", "ill4096_grad", "si24000_bcm16_tail", "tail4096_ll", "ill4096_ll", "cg_sine1024",
+           "tail2048_grad", "ill2048_grad", "tail2048_ll", "ill2048_ll"]    # round 3 (written into golden_r2/ too)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
@@ -281,6 +319,9 @@ if __name__ == "__main__":
     from oracle.oracle_py import Reference, build
     if a.job == "list":
         print("\n".join(JOBS))
+        raise SystemExit(0)
+    if a.job == "list3":
+        print("\n".join(JOBS_R3))
         raise SystemExit(0)
     if a.job == "data":
         make_data()

@@ -1,6 +1,8 @@
 // chain_bench.hip -- times the latency-critical kernels of the Cholesky chain alone (potf2, strip TRSM,
 // next-diagonal update) and prints in-kernel cycle stamps of potf2.  Diagnostic build: -DCUGP_STAMPS.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DCUGP_STAMPS -I cugp_amd/csrc tools/chain_bench.hip -o tools/bin/chain_bench
+#pragma clang diagnostic ignored "-Wunused-result"
+#pragma clang diagnostic ignored "-Wunused-value"
 #include "../cugp_amd/csrc/kernels.hip"
 
 #include <cstdio>
@@ -48,12 +50,16 @@ int main()
     float t_copy = timeit(copy_only, &c, 50);
     float t_potf2 = timeit(potf2, &c, 50);
     printf("potf2 (128x128 diagonal block): %.2f us (incl. %.2f us restore copy)\n", t_potf2, t_copy);
-    unsigned long long st[64];
+    unsigned long long st[128];
     hipMemcpyFromSymbol(st, HIP_SYMBOL(g_stamps), sizeof st);
-    printf("  stamps (cycles): load %llu | panel factor 0 %llu\n", st[1] - st[0], st[2] - st[1]);
-    for (int jb = 0; jb < 7; jb++)
-        printf("  jb=%d: update of column jb+1 %llu   panel factor jb+1 beside the rest of the update %llu\n", jb,
-               st[3 + 3 * jb] - (jb ? st[4 + 3 * (jb - 1)] : st[2]), st[4 + 3 * jb] - st[3 + 3 * jb]);
+    printf("  stamps (cycles): load %llu\n", st[1] - st[0]);
+    for (int q = 0; q < 8; q++)
+        printf("  q=%d: panel factor beside the older panels' update of column q+1 %llu   panel q into column q+1 %llu\n", q,
+               st[2 + 2 * q] - (q ? st[1 + 2 * q] : st[1]), st[3 + 2 * q] - st[2 + 2 * q]);
+    for (int q = 0; q < 8; q++)
+        printf("  q=%d: waves reach the barrier after %lld %lld %lld %lld cycles\n", q, (long long)(st[64 + 4 * q] - (q ? st[1 + 2 * q] : st[1])),
+               (long long)(st[65 + 4 * q] - (q ? st[1 + 2 * q] : st[1])), (long long)(st[66 + 4 * q] - (q ? st[1 + 2 * q] : st[1])),
+               (long long)(st[67 + 4 * q] - (q ? st[1 + 2 * q] : st[1])));
     printf("  store of the off-diagonal tiles %llu | logdet %llu | 64x64 inverses %llu | total %llu cycles\n", st[31] - st[30],
            st[32] - st[31], st[33] - st[32], st[33] - st[0]);
 
