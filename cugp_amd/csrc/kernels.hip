@@ -794,8 +794,13 @@ __device__ __forceinline__ void panel_load(double* __restrict__ sm, int jb, int 
     for (int c = 0; c < MT; c++) r[c] = pl.myrow[c];
 }
 
+// arrive / arrive_target (when arrive_target > 0: several waves factor this panel): every factoring wave counts itself
+// in *arrive once its copy of the diagonal tile is in registers; the wave with the identity rows overwrites the tile
+// in LDS with the inverse only after it has seen all of them (a bounded wait that is over long before it is reached:
+// the store comes 16 pivots after the loads) -- no workgroup barrier between panel_load and panel_factor.
 __device__ __forceinline__ void panel_factor(const PanelLanes& pl, double (&r)[MT], double* __restrict__ gdiag, int ld,
-                                              double* __restrict__ rinv, const double* colbuf)
+                                              double* __restrict__ rinv, const double* colbuf, unsigned* arrive,
+                                              unsigned arrive_target)
 {
     // (colbuf is written through pl.wslot: no __restrict__)
     // Software-pipelined by hand, one wave issues in order: the next pivot's v_rsq goes out FIRST, the bulk of the
@@ -804,6 +809,11 @@ __device__ __forceinline__ void panel_factor(const PanelLanes& pl, double (&r)[M
     // and the broadcast of m_(c+2) start.  sched_barriers keep the compiler from sinking the bulk in front of the rsq.
     const int lane = threadIdx.x & 63;
     double piv = readlane_f64(r[0], 0);
+    if (arrive_target > 0) {
+        // (r[15], the last value panel_load asked for, is in its register: LDS returns a wave's reads in order)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     double ys[MT];
     d2 mm[2][MT / 2];                                  // uniform column entries m_j of the pivot in flight / the one before
     double ltp = 0.0;                                  // -(m / d) of the previous pivot
@@ -870,11 +880,15 @@ __device__ __forceinline__ void panel_factor(const PanelLanes& pl, double (&r)[M
 #pragma unroll
         for (int c = 0; c < MT; c++) pl.myrow[c] = r[c];
     } else if (pl.kind == 2) {
-        // my row is column idx of L_jj^-1: the inverse replaces the diagonal tile in LDS (every factoring wave took its
-        // copy of the tile before the barrier in front of this call; the factor itself goes to global memory below)
+        // my row is column idx of L_jj^-1: the inverse replaces the diagonal tile in LDS (the factor itself goes to
+        // global memory from the owner's registers)
+        if (arrive_target > 0) {
+            for (int spin = 0; spin < (1 << 20); spin++)
+                if (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= arrive_target) break;
+        }
 #pragma unroll
         for (int c = 0; c < MT; c++) pl.icol[c * (MT + 1)] = r[c];
-    } else if (gdiag) {                                                  // the owner wave: the factor's diagonal tile is final
+    } else if (pl.kind == 0 && gdiag) {                                  // the owner wave: the factor's diagonal tile is final
         double* g = gdiag + (size_t)lane * ld;
         // (entries above the diagonal of a diagonal micro tile are never read on the device, and cugp_get_cholesky
         //  zeroes the strict upper triangle on the host: no masking)
@@ -1094,7 +1108,7 @@ __device__ __forceinline__ unsigned helper_tasks(int q, int h)
 {
 #define CUGP_T(bi0, bi1, bj, p0, p1) ((unsigned)((bi0) | (bi1) << 3 | (bj) << 6 | (p0) << 9 | (p1) << 12))
     switch (q * 4 + h) {
-    case 1 * 4 + 0: return CUGP_T(2, 7, 2, 0, 1);                                      // 24 MFMAs (the only helper)
+    case 1 * 4 + 0: return CUGP_T(3, 7, 2, 0, 1);                                      // 20 MFMAs (the only helper; tile (2,2) rode in U1(0))
     case 2 * 4 + 0: return CUGP_T(3, 5, 3, 0, 2);                                      // 24
     case 2 * 4 + 1: return CUGP_T(6, 7, 3, 0, 2) | CUGP_T(7, 7, 5, 0, 2) << 16;        // 16 + 8 (ahead of phase 4)
     case 3 * 4 + 0: return CUGP_T(4, 5, 4, 0, 3);                                      // 24
@@ -1116,6 +1130,8 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ Ab, int ld, doub
     double* rinv = sm + NLT * MTS;                          // 1 / L_ii, 128 entries
     double* colbuf = red;                                   // pivot columns: 2 x 16 doubles for each of the 4 waves
     double* zz = red + TILE;                                // delta vector + parking slots of the identity rows (panel_load)
+    unsigned* arrive = (unsigned*)(zz + 2 * MT - 1);        // factoring waves that hold their copy of the diagonal tile (panel_factor)
+    unsigned arrived = 0;                                   // ... expected once every wave of the phases so far has counted itself
     (void)d16blk;                                           // (16x16 inverses live in LDS only)
     // (the wave index through readfirstlane: the compiler then knows that everything decided by it -- which tiles
     //  a wave updates, which rows it factors -- is wave-uniform and keeps that control flow on the scalar unit)
@@ -1133,7 +1149,7 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ Ab, int ld, doub
             for (int bj = 0; bj <= bi; bj++) v[bi * (bi + 1) / 2 + bj] = Ab[(size_t)(bi * MT + r) * ld + bj * MT + c];
 #pragma unroll
         for (int q = 0; q < NLT; q++) sm[q * MTS + r * (MT + 1) + c] = v[q];
-        if (t < 2 * MT) zz[t] = t == MT - 1 ? 1.0 : 0.0;
+        if (t < 2 * MT) zz[t] = t == MT - 1 ? 1.0 : 0.0;    // (zz[31], never read as a double, is the arrival counter: 0)
     }
     __syncthreads();
     STAMP(1);
@@ -1146,88 +1162,159 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ Ab, int ld, doub
     PanelLanes pl;
     double pr[MT];
     double* gblk = Ab;                                       // global home of the 128x128 block (row stride ld)
+    const d4 zero4 = (d4){0.0, 0.0, 0.0, 0.0};
+    d4 hw0 = zero4, hw1 = zero4;                            // products a helper wave carries across a barrier
+    // one off-diagonal micro tile of the factor back to global memory, by one wave (its LDS home is about to be
+    // overwritten by a piece of an inverse, or the wave has nothing else to do)
+    auto store_tile = [&](int bi, int bj) {
+        const int lane = t & 63, r = lane >> 3, c = (lane & 7) * 2;             // two adjacent entries per lane: 16-byte stores
+        const double* src = sm + mt_off(bi, bj) + r * (MT + 1) + c;
+        double* dst = Ab + (size_t)(bi * MT + r) * ld + bj * MT + c;
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+            *(d2*)(dst + (size_t)(8 * k) * ld) = (d2){src[8 * k * (MT + 1)], src[8 * k * (MT + 1) + 1]};
+    };
+    // 16 -> 32: T21 = -T_B (L21 T_A) for the pair of diagonal micro tiles a = 2p, b = 2p + 1, in place of tile (b,a)
+    auto pair_double = [&](int p2) {
+        const int a = 2 * p2, b = 2 * p2 + 1;
+        store_tile(b, a);
+        const d4 w = micro_mma_nn(sm + mt_off(b, a), sm + mt_off(a, a), zero4);
+        const d4 t21 = micro_mma_acc_b(sm + mt_off(b, b), w, zero4);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        micro_store(sm + mt_off(b, a), t21);
+    };
+    // 32 -> 64 of 64-block h, column bj of its lower-left 2x2 micro tiles, first half:
+    // W(kb', bj) = sum_{jb' >= bj} C(kb', jb') T_A(jb', bj)  (reads only)
+    auto block_w = [&](int h, int bj, d4& w0, d4& w1) {
+        const int a0 = 4 * h, b0 = 4 * h + 2;
+        w0 = zero4; w1 = zero4;
+        for (int jp = bj; jp < 2; jp++) {
+            w0 = micro_mma_nn(sm + mt_off(b0, a0 + jp), sm + mt_off(a0 + jp, a0 + bj), w0);
+            w1 = micro_mma_nn(sm + mt_off(b0 + 1, a0 + jp), sm + mt_off(a0 + jp, a0 + bj), w1);
+        }
+    };
+    // ... second half: T(b0 + i, a0 + bj) = -sum_{k <= i} T_B(i, k) W(k, bj)  (t0, t1 still to be stored)
+    auto block_t = [&](int h, const d4& w0, const d4& w1, d4& t0, d4& t1) {
+        const int b0 = 4 * h + 2;
+        t0 = micro_mma_acc_b(sm + mt_off(b0, b0), w0, zero4);
+        t1 = micro_mma_acc_b(sm + mt_off(b0 + 1, b0), w0, zero4);
+        t1 = micro_mma_acc_b(sm + mt_off(b0 + 1, b0 + 1), w1, t1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    auto block_store = [&](int h, int bj, const d4& t0, const d4& t1) {
+        micro_store(sm + mt_off(4 * h + 2, 4 * h + bj), t0);
+        micro_store(sm + mt_off(4 * h + 3, 4 * h + bj), t1);
+    };
+    // one 64x64 inverse to global, row-major (micro tiles above the diagonal are never read), by nw waves from wave w0
+    auto store_d64 = [&](int h, int w0, int nw) {
+        const int u = t - w0 * 64, nth = nw * 64;
+#pragma unroll 5
+        for (int q = 0; q < 10; q++) {
+            const int bi = q < 1 ? 0 : (q < 3 ? 1 : (q < 6 ? 2 : 3)), bj = q - bi * (bi + 1) / 2;
+            for (int e = u; e < 128; e += nth) {                                // 128 pairs of adjacent entries per tile
+                const int r = e >> 3, c = (e & 7) * 2;
+                const double* src = sm + mt_off(4 * h + bi, 4 * h + bj) + r * (MT + 1) + c;
+                *(d2*)(d64blk + (size_t)h * 4096 + (bi * MT + r) * 64 + bj * MT + c) = (d2){src[0], src[1]};
+            }
+        }
+    };
     for (int q = 0; q < NMT; q++) {
         const int rows = (NMT - 1 - q) * MT, iw = rows / 48;
-        if (wave <= iw) panel_load(sm, q, rows, wave * 48, wave == iw, colbuf + wave * 2 * MT, zz, pl, pr);
-        lds_barrier();                                      // every factoring wave has its copy of the diagonal tile
         if (wave <= iw) {
+            panel_load(sm, q, rows, wave * 48, wave == iw, colbuf + wave * 2 * MT, zz, pl, pr);
             double* gd = wave == 0 ? gblk + (size_t)q * MT * ld + q * MT : nullptr;
-            panel_factor(pl, pr, gd, ld, rinv + q * MT, colbuf + wave * 2 * MT);
+            panel_factor(pl, pr, gd, ld, rinv + q * MT, colbuf + wave * 2 * MT, arrive, iw > 0 ? arrived + iw + 1 : 0u);
         } else {
-            unsigned code = helper_tasks(q, wave - iw - 1);
+            const int h = wave - iw - 1;
+            unsigned code = helper_tasks(q, h);
             for (; code & 0x7fffu; code >>= 16) {
                 const int bi1 = code >> 3 & 7, bj = code >> 6 & 7, p0 = code >> 9 & 7, p1 = code >> 12 & 7;
                 int bi = code & 7;
                 for (; bi + 1 <= bi1; bi += 2) micro_update_multi<2>(sm, bi, bj, p0, p1);
                 if (bi <= bi1) micro_update_multi<1>(sm, bi, bj, p0, p1);
             }
+            // The spare time of the helpers in the last phases goes to what used to follow the factorisation: the
+            // finished columns of the factor back to global memory, and the doubling of the 16x16 inverses
+            // (16 -> 32 -> 64) as far as the finished diagonal tiles allow.  A tile is stored before a piece of an
+            // inverse takes its place in LDS; every such piece is read only from the next phase on (barriers between).
+            if (q == 4 && h == 1) pair_double(0);
+            if (q == 5) {                                           // columns 0..3 of the factor are final
+                if (h == 2) {
+#pragma nounroll
+                    for (int bj = 0; bj < 2; bj++)
+#pragma unroll 3
+                        for (int bi = 2; bi < NMT; bi++) store_tile(bi, bj);    // ((1,0) went out with its pair in phase 4)
+                    pair_double(1);                                 // (stores (3,2) itself)
+                } else {
+                    const int bj = 2 + h;                           // h = 0: column 2 below (3,2); h = 1: column 3
+#pragma unroll 4
+                    for (int bi = 4; bi < NMT; bi++) store_tile(bi, bj);
+                }
+            }
+            if (q == 6 && h >= 1) {                                 // 64-block 0: column bj = h - 1
+                block_w(0, h - 1, hw0, hw1);
+                d4 t0, t1;
+                block_t(0, hw0, hw1, t0, t1);
+                // column 0 at once (wave h = 2 reads only column 1 of these tiles); column 1 after the barrier
+                // (wave h = 1 reads it)
+                if (h == 1) block_store(0, 0, t0, t1);
+                else { hw0 = t0; hw1 = t1; }
+            }
+            if (q == 7) {
+                if (h == 0) { pair_double(2); block_w(1, 0, hw0, hw1); }      // (4,5), then W(., 0) of 64-block 1
+                if (h == 1) { block_w(1, 1, hw0, hw1); store_d64(0, 2, 1); }
+                if (h == 2) {
+                    store_tile(6, 4); store_tile(7, 4); store_tile(6, 5); store_tile(7, 5); store_tile(7, 6);
+                    hw0 = micro_mma_nn(sm + mt_off(7, 6), sm + mt_off(6, 6), zero4);   // first half of the pair (6,7)
+                    // log-determinant share of the first seven diagonal tiles: sum_i log(1/L_ii), i < 112, fixed order
+                    const int lane = t & 63;
+                    double v = log(rinv[lane]) + (lane < 48 ? log(rinv[lane + 64]) : 0.0);
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+                    if (lane == 0) colbuf[3 * 2 * MT] = v;          // (this wave's column buffer is idle: it never factors)
+                }
+            }
         }
+        if (iw > 0) arrived += iw + 1;
         WSTAMP(64 + q * 4 + wave);                         // (diagnostic build: when each wave reaches the barrier)
         lds_barrier();
         STAMP(2 + 2 * q);
+        if (q == 6 && wave == 3) block_store(0, 1, hw0, hw1);
         if (q + 1 < NMT) {
-            micro_update_run(sm, q, wave, 4, NMT - 1 - q);  // U1: column q+1 = tiles 0 .. m-1 of panel q's update
+            // U1: panel q into column q+1 = tiles 0 .. m-1 of its update (phase 0: and tile (2,2), for the one wave
+            // that would otherwise hold a single tile)
+            micro_update_run(sm, q, wave, 4, NMT - 1 - q + (q == 0 ? 1 : 0));
             lds_barrier();
         }
         STAMP(3 + 2 * q);
     }
-
+    lds_barrier();                                          // the last tile's inverse is in LDS
     STAMP(30);
-    {   // the rest of the factor back to global (the diagonal micro tiles went there as they were factored; their
-        // LDS copies now hold the 16x16 inverses)
-        const int r = t >> 4, c = t & 15;
-        for (int bi = 1; bi < NMT; bi++)
-            for (int bj = 0; bj < bi; bj++)
-                Ab[(size_t)(bi * MT + r) * ld + bj * MT + c] = sm[mt_off(bi, bj) + r * (MT + 1) + c];
+    // what is left of the inverses: second half of the pair (6,7), then of 64-block 1 (its W came from phase 7)
+    if (wave == 3) {
+        const d4 t21 = micro_mma_acc_b(sm + mt_off(7, 7), hw0, zero4);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        micro_store(sm + mt_off(7, 6), t21);
     }
-    // LDS has been read (the stores themselves stay in flight: a __syncthreads here would wait ~4k cycles for them)
+    // log-determinant share of this block: sum_i log L_ii = -sum_i log(1/L_ii); the last tile's 16 terms join the
+    // partial sum of phase 7 (fixed order)
+    if (wave == 0) {
+        const int lane = t & 63;
+        double v = lane < MT ? log(rinv[TILE - MT + lane]) : 0.0;
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if (lane == 0) *logdet_out = -(colbuf[3 * 2 * MT] + v);
+    }
     lds_barrier();
     STAMP(31);
-    // log-determinant share of this block: sum_i log L_ii = -sum_i log(1/L_ii), 128 terms by one wave in a fixed order
-    if (wave == 3) {
-        const int lane = t & 63;
-        double v = -(log(rinv[lane]) + log(rinv[lane + 64]));
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-        if (lane == 0) *logdet_out = v;
+    if (wave == 1 || wave == 2) {
+        d4 t0, t1;
+        block_t(1, hw0, hw1, t0, t1);
+        block_store(1, wave - 1, t0, t1);
     }
+    lds_barrier();
     STAMP(32);
-    // ---- inverses of the two 64x64 diagonal sub-blocks from the 16x16 ones, in place (the sub-diagonal tiles they
-    // overwrite are on their way to global memory: the doubling below reads them first, barriers in between) ----
-    // used by the panel solve: 3 short MFMA phases per strip instead of a 144-long dependent chain.
-    const d4 zero4 = (d4){0.0, 0.0, 0.0, 0.0};
-    {   // 16 -> 32: pair p = wave: T21 = -T_B (L21 T_A)
-        const int a = 2 * wave, b = 2 * wave + 1;
-        d4 w = micro_mma_nn(sm + mt_off(b, a), sm + mt_off(a, a), zero4);
-        d4 t21 = micro_mma_acc_b(sm + mt_off(b, b), w, zero4);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        micro_store(sm + mt_off(b, a), t21);
-    }
-    __syncthreads();
-    {   // 32 -> 64: 64-block h = wave >> 1, column bj = wave & 1 of its lower-left 2x2 micro tiles
-        const int h = wave >> 1, bj = wave & 1, a0 = 4 * h, b0 = 4 * h + 2;
-        d4 w0 = zero4, w1 = zero4;                      // W(kb', bj) = sum_{jb' >= bj} C(kb', jb') T_A(jb', bj)
-        for (int jp = bj; jp < 2; jp++) {
-            w0 = micro_mma_nn(sm + mt_off(b0, a0 + jp), sm + mt_off(a0 + jp, a0 + bj), w0);
-            w1 = micro_mma_nn(sm + mt_off(b0 + 1, a0 + jp), sm + mt_off(a0 + jp, a0 + bj), w1);
-        }
-        __syncthreads();                                // every wave has read its C tiles
-        d4 t0 = micro_mma_acc_b(sm + mt_off(b0, b0), w0, zero4);                // bi = 0: k' = 0
-        d4 t1 = micro_mma_acc_b(sm + mt_off(b0 + 1, b0), w0, zero4);            // bi = 1: k' = 0, 1
-        t1 = micro_mma_acc_b(sm + mt_off(b0 + 1, b0 + 1), w1, t1);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        micro_store(sm + mt_off(b0, a0 + bj), t0);
-        micro_store(sm + mt_off(b0 + 1, a0 + bj), t1);
-    }
-    __syncthreads();
-    {   // the two inverses to global, row-major 64x64 each (micro tiles above the diagonal are never read)
-        const int r = t >> 4, c = t & 15;
-        for (int h = 0; h < 2; h++)
-            for (int bi = 0; bi < 4; bi++)
-                for (int bj = 0; bj <= bi; bj++)
-                    d64blk[(size_t)h * 4096 + (bi * MT + r) * 64 + bj * MT + c] =
-                        sm[mt_off(4 * h + bi, 4 * h + bj) + r * (MT + 1) + c];
-    }
+    store_d64(1, 0, 4);
     STAMP(33);
 }
 

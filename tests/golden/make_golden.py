@@ -255,14 +255,15 @@ def job(r, name):
             out["cases"].append({"hp": hp, "ll": ll, "ll_per_expert_6dp": per, "grad": g.tolist(), "Xt": Xt.tolist(),
                                  "yt": yt.tolist(), "pred_mean": m.tolist(), "pred_var": v.tolist(),
                                  "nlpp": b.nlpp(yt, m, v)})
-    elif name in ("si24000_bcm16_tail",):
-        # round 3: config 5 at the hyper-parameters the reference's CG ends at (REF:3167-3183)
+    elif name in ("si24000_bcm16_tail", "si24000_bcm16_ill"):
+        # round 3: config 5 at the hyper-parameters the reference's CG ends at (REF:3167-3183), and ill-conditioned
         X, y = _rows("si24000")
-        b = r.bcm(X, y, 16, HP_TAIL)
+        HP_T = HP_TAIL if name.endswith("tail") else HP_ILL
+        b = r.bcm(X, y, 16, HP_T)
         log = os.path.join(tempfile.mkdtemp(), "ll.log")
         ll = b.loglik(log)
         per = [float(m.group(1)) for m in re.finditer(r"LL of Expert \d+: ([-\d.]+)", open(log).read())]
-        out = {"K": 16, "rows": [0, 24000], "hp": HP_TAIL, "ll": ll, "ll_per_expert_6dp": per,
+        out = {"K": 16, "rows": [0, 24000], "hp": HP_T, "ll": ll, "ll_per_expert_6dp": per,
                "grad": b.grad().tolist()}
     elif name == "cg_sine1024":
         # round 3: a cg_solve trajectory above 256 rows (covkernel.cpp:405-647)
@@ -290,11 +291,11 @@ def job(r, name):
         else:
             out["grad"] = r.grad(X, y, hp).tolist()
     else:
-        m = re.match(r"(d8192|s10000|si6000_\d)_(ll|grad)(_two)?$", name)
+        m = re.match(r"(d8192|s10000|si6000_\d)_(ll|grad)(_two|_ill)?$", name)
         if not m:
             raise SystemExit("unknown job " + name)
         X, y = _rows(m.group(1))
-        hp = HP_TWO if m.group(3) else HP_DENSE
+        hp = HP_TWO if m.group(3) == "_two" else (HP_ILL if m.group(3) == "_ill" else HP_DENSE)
         out = {"rows": m.group(1), "n": int(X.shape[0]), "hp": hp}
         if m.group(2) == "ll":
             out["ll"] = r.loglik(X, y, hp)
@@ -309,7 +310,8 @@ def job(r, name):
 JOBS = (["s10000_grad", "d8192_grad", "s10000_ll"] + ["si6000_%d_grad" % k for k in range(4)] + ["d8192_ll"]
         + ["si6000_%d_ll" % k for k in range(4)] + ["si24000_bcm16"])      # longest first
 JOBS_R3 = ["tail4096_grad", "ill4096_grad", "si24000_bcm16_tail", "tail4096_ll", "ill4096_ll", "cg_sine1024",
-           "tail2048_grad", "ill2048_grad", "tail2048_ll", "ill2048_ll"]    # round 3 (written into golden_r2/ too)
+           "tail2048_grad", "ill2048_grad", "tail2048_ll", "ill2048_ll",
+           "d8192_grad_ill", "d8192_ll_ill", "si24000_bcm16_ill"]           # round 3 (written into golden_r2/ too)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

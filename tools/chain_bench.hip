@@ -60,8 +60,8 @@ int main()
         printf("  q=%d: waves reach the barrier after %lld %lld %lld %lld cycles\n", q, (long long)(st[64 + 4 * q] - (q ? st[1 + 2 * q] : st[1])),
                (long long)(st[65 + 4 * q] - (q ? st[1 + 2 * q] : st[1])), (long long)(st[66 + 4 * q] - (q ? st[1 + 2 * q] : st[1])),
                (long long)(st[67 + 4 * q] - (q ? st[1 + 2 * q] : st[1])));
-    printf("  store of the off-diagonal tiles %llu | logdet %llu | 64x64 inverses %llu | total %llu cycles\n", st[31] - st[30],
-           st[32] - st[31], st[33] - st[32], st[33] - st[0]);
+    printf("  tail: second half of the pair (6,7) + logdet %llu | second half of 64-block 1 %llu | its store %llu | total %llu cycles\n",
+           st[31] - st[30], st[32] - st[31], st[33] - st[32], st[33] - st[0]);
 
     auto trsm2 = [](void* p) { Ctx* c = (Ctx*)p; launch_trsm_inv64(c->A, c->d64, c->n, 0, c->nt, 0); };
     printf("trsm_inv64 (%d strips): %.2f us\n", (nt - 1) * 8, timeit(trsm2, &c, 50));

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(256) void k_panel(const double* __restrict__ A, int
     if (wave <= 2) panel_load(sm, 0, rows, wave * 48, wave == 2, red + wave * 2 * MT, zz, pl, pr);
     lds_barrier();
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
-    if (wave <= 2) panel_factor(pl, pr, wave == 0 ? gd : nullptr, TILE, rinv, red + wave * 2 * MT);
+    if (wave <= 2) panel_factor(pl, pr, wave == 0 ? gd : nullptr, TILE, rinv, red + wave * 2 * MT, (unsigned*)(zz + 2 * MT - 1), 3u);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t2)::"memory");
     lds_barrier();
     if ((t & 63) == 0) { cyc[wave * 2] = t1 - t0; cyc[wave * 2 + 1] = t2 - t1; }
