@@ -262,9 +262,8 @@ int fork_inverse_block(cugp_gp* g, int a, int b, int idx, hipStream_t from)
 // brought up to date by every earlier wide pass.  Once the window reaches the last column (small trailing
 // matrices, where the chain is the bound anyway) this IS the classic right-looking form.
 struct StepPlan {
-    int wide_k0, wide_kw;      // k tiles of the wide update issued at this step (after its panel solve) ...
-    int wa0, wa1, wb0, wb1;    // ... over the tile columns [wa0, wa1) (event after it), then [wb0, wb1); empty: none
-    int wait_panel;            // >= 0: the step launch waits for the first wide launch of that panel (two-stream form)
+    int wide_k0, wide_kw;      // k tiles of the wide update issued behind this step's launch ...
+    int wa0, wa1;              // ... over the tile columns [wa0, wa1); empty: none
     int wcol, la0, kfirst;     // step launch: columns [kb+1, kb+1+wcol); columns >= la0 take k tiles [kfirst, kb]
 };
 
@@ -300,7 +299,7 @@ int far_boundary(int nt, int P, int near, int p)
 
 StepPlan plan_step(int nt, int P, int near, int kb)
 {
-    StepPlan sp{0, 0, 0, 0, 0, 0, -1, nt - kb - 1, 1 << 30, kb};
+    StepPlan sp{0, 0, 0, 0, nt - kb - 1, 1 << 30, kb};
     if (P <= 1) return sp;                                            // classic: the whole trailing matrix, k = kb
     const int p = kb / P, i = kb % P;
     const int F = far_boundary(nt, P, near, p);
@@ -405,9 +404,7 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false)
     const int P = panel_width(g);
     const int near = g_tune[TUNE_NEAR_TILES];
     if (w > 0 && (rc = ensure_inverse_streams(g))) return rc;
-    // everything on the handle's stream; the wide passes optionally on a stream of their own (the step launch
-    // that follows still waits for them: that form only moves them to another hardware queue)
-    hipStream_t m = g->stream, wq = g_tune[TUNE_WIDE_STREAM] != 0 ? g->wide : g->stream;
+    hipStream_t m = g->stream;                              // the whole factorisation is ordered on the handle's stream
     int nblk = 0, done = 0;                                 // blocks forked so far, block rows handed over
     // Small matrices: every hand-over costs the main stream a ~11-us bubble (event record + cross-stream wait) and the
     // chip is mostly idle anyway, so the first nt - 2w block rows go over in ONE block, late, and only the last two
@@ -417,7 +414,6 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false)
     // start (16 x 1500: +4 % when late; 2 x 1500, 5 x 1000: -2...-3 %): at most 64 tile rows over the whole group.
     const int group_rows = nt * (g->grp ? g->grp->bt.count : 1);
     const int first = (w > 0 && nt <= g_tune[TUNE_LATE_FORK_NT] && group_rows <= 64 && nt - 2 * w > w) ? nt - 2 * w : w;
-    bool wide_used = false;
     g->eval_seq++;
     if (g->grp) HIPCHK(hipMemsetAsync(g->grp->tickets, 0, (size_t)g->grp->bt.count * nt * sizeof(unsigned), m));
     else HIPCHK(hipMemsetAsync(g->dtickets, 0, (size_t)nt * sizeof(unsigned), m));
@@ -433,30 +429,12 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false)
         }
         const StepPlan sp = plan_step(nt, P, near, kb);
         if (sp.wa1 > sp.wa0) {
-            // panel p is factored (its last panel solve is enqueued): everything beyond the look-ahead columns
-            // gets the panel's K = P*128 in one pass -- first the columns the NEXT panel's steps will touch
-            const int p = kb / P;
-            if (wq != m) {
-                HIPCHK(hipEventRecord(g->pnev[p], m));
-                HIPCHK(hipStreamWaitEvent(wq, g->pnev[p], 0));
-            }
-            {
-                TimedLaunch tl(g, wq, g->prof >= 2);
-                launch_syrk_wide(g->dA, ld, nt, sp.wide_k0, sp.wide_kw, sp.wa0, sp.wa1, p & 1, wq, B(g));
-                tl.done(1, trailing_flop(nt, sp.wa0, sp.wa1, sp.wide_kw));
-            }
-            if (wq != m) {                                      // two-stream form: the next step launch must see it done
-                HIPCHK(hipEventRecord(g->wev[p], wq));
-                HIPCHK(hipStreamWaitEvent(m, g->wev[p], 0));
-            }
-            if (sp.wb1 > sp.wb0) {
-                TimedLaunch tl(g, wq, g->prof >= 2);
-                launch_syrk_wide(g->dA, ld, nt, sp.wide_k0, sp.wide_kw, sp.wb0, sp.wb1, p & 1, wq, B(g));
-                tl.done(1, trailing_flop(nt, sp.wb0, sp.wb1, sp.wide_kw));
-            }
-            wide_used = true;
+            // panel p is factored (its last panel solve is enqueued): the far columns get the panel's K = P*128 in
+            // one pass, before the next panel's first step widens the near window into them
+            TimedLaunch tl(g, m, g->prof >= 2);
+            launch_syrk_wide(g->dA, ld, nt, sp.wide_k0, sp.wide_kw, sp.wa0, sp.wa1, (kb / P) & 1, m, B(g));
+            tl.done(1, trailing_flop(nt, sp.wa0, sp.wa1, sp.wide_kw));
         }
-        if (sp.wait_panel >= 0) HIPCHK(hipStreamWaitEvent(m, g->wev[sp.wait_panel], 0));   // that wide update is done with the look-ahead columns
         // level 2 times a rotating eighth of the step launches (every step is sampled once in 8 evaluations):
         // an event pair around every launch costs several percent of the evaluation
         TimedLaunch tl(g, m, g->prof >= 2 && (kb + g->eval_seq) % PROF_STRIDE == 0);
@@ -466,10 +444,6 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false)
                          P > 1 ? g_tune[TUNE_STEP_STREAM] : 1);
         tl.done(0, trailing_flop(nt, kb + 1, sp.la0 < kb + 1 + sp.wcol ? sp.la0 : kb + 1 + sp.wcol, 1) +
                        trailing_flop(nt, sp.la0, kb + 1 + sp.wcol, kb + 1 - sp.kfirst));
-    }
-    if (wide_used && wq != m) {                             // (every wide launch was already waited for; this join
-        HIPCHK(hipEventRecord(g->wev.back(), wq));          //  keeps the stream graph closed)
-        HIPCHK(hipStreamWaitEvent(m, g->wev.back(), 0));
     }
     if (mark && (rc = phase_mark(g, 2))) return rc;         // end of the factorisation on the main stream
     if (w > 0) {
@@ -1255,7 +1229,7 @@ int cugp_potrf_plan(int nt, int P, int near, int kb, int out[10])
 {
     if (!out || nt <= 1 || kb < 0 || kb + 1 >= nt || P < 1) return CUGP_ERR_INVALID;
     const StepPlan sp = plan_step(nt, P, near, kb);
-    const int v[10] = {sp.wide_k0, sp.wide_kw, sp.wa0, sp.wa1, sp.wb0, sp.wb1, sp.wait_panel, sp.wcol, sp.la0, sp.kfirst};
+    const int v[10] = {sp.wide_k0, sp.wide_kw, sp.wa0, sp.wa1, 0, 0, -1, sp.wcol, sp.la0, sp.kfirst};
     for (int i = 0; i < 10; i++) out[i] = v[i];
     return CUGP_OK;
 }

@@ -499,39 +499,55 @@ __global__ __launch_bounds__(256) void k_mfma_peak(double* sink, int iters)
 //   X0 = A0 T00^T ;  Z1 = A1 - X0 L10^T ;  X1 = Z1 T11^T
 // one workgroup (4 waves) per strip, wave w owns the 16-column tile w of each half; everything is kept
 // transposed so results in C/D layout are the next product's B operand (k = (lane>>4) + 4*reg); the
-// tiles the other waves need pass through 8 KiB of LDS.  <= 48 dependent MFMAs per wave (was 144).
+// tiles the other waves need pass through 8 KiB of LDS.  <= 48 dependent MFMAs per wave.
+// Every operand of the three phases is requested before the first MFMA (68 doubles per lane): the strip used to
+// pay a global-memory latency per phase and per k tile (the loads sat inside loops with a wave-dependent trip
+// count); entries of the inverses above the diagonal micro tiles are loaded but never multiplied.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_trsm_inv64(double* __restrict__ A, const double* __restrict__ d64,
-                                                    int ld, int kb, const ExpertPtrs* __restrict__ bt)
+__device__ __forceinline__ void strip_solve(double* __restrict__ A, const double* __restrict__ d64, int ld, int kb,
+                                            int strip, double (*xbuf)[4][64])
 {
-    if (bt) { A = GP(bt[blockIdx.y].A); d64 = GP(bt[blockIdx.y].d64); }
-    __shared__ double xbuf[4][4][64];
-    __builtin_amdgcn_s_setprio(3);                      // on the factorisation's serial chain (see k_syrk_step)
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 15, g = lane >> 4;
     const int k0 = kb * TILE;
-    double* Arow = A + (size_t)(k0 + TILE + blockIdx.x * MT + c) * ld + k0;   // my row of the strip (as B operand / output)
-    const double* T00 = d64 + (size_t)kb * 8192;
+    double* Arow = A + (size_t)(k0 + TILE + strip * MT + c) * ld + k0;   // my row of the strip (as B operand / output)
+    const double* T00 = d64 + (size_t)kb * 8192 + (w * MT + c) * 64 + g;
     const double* T11 = T00 + 4096;
-    const double* L10 = A + (size_t)(k0 + 64) * ld + k0;
+    const double* L10 = A + (size_t)(k0 + 64 + w * MT + c) * ld + k0 + g;
     const d4 zero4 = (d4){0.0, 0.0, 0.0, 0.0};
-
+    double t00[4][4], t11[4][4], a0[4][4], l10[4][4];
+    d4 z;
+#pragma unroll
+    for (int kt = 0; kt < 4; kt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            t00[kt][r] = T00[kt * MT + 4 * r];
+            a0[kt][r] = Arow[kt * MT + g + 4 * r];
+        }
+#pragma unroll
+    for (int r = 0; r < 4; r++) z[r] = Arow[64 + w * MT + g + 4 * r];
+#pragma unroll
+    for (int kt = 0; kt < 4; kt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            l10[kt][r] = -L10[kt * MT + 4 * r];
+            t11[kt][r] = T11[kt * MT + 4 * r];
+        }
     // phase 1: X0^T[w] = sum_{kt <= w} T00[w][kt] A0^T[kt]
     // (each phase runs two independent accumulation chains: a dependent fp64 MFMA chain issues at half rate)
     d4 x0 = zero4, x0b = zero4;
-    for (int kt = 0; kt <= w; kt++) {
 #pragma unroll
-        for (int r = 0; r < 4; r += 2) {
-            x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(T00[(w * MT + c) * 64 + kt * MT + g + 4 * r],
-                                                      Arow[kt * MT + g + 4 * r], x0, 0, 0, 0);
-            x0b = __builtin_amdgcn_mfma_f64_16x16x4f64(T00[(w * MT + c) * 64 + kt * MT + g + 4 * (r + 1)],
-                                                       Arow[kt * MT + g + 4 * (r + 1)], x0b, 0, 0, 0);
+    for (int kt = 0; kt < 4; kt++)
+        if (kt <= w) {
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+                x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(t00[kt][r], a0[kt][r], x0, 0, 0, 0);
+                x0b = __builtin_amdgcn_mfma_f64_16x16x4f64(t00[kt][r + 1], a0[kt][r + 1], x0b, 0, 0, 0);
+            }
         }
-    }
     x0 += x0b;
-    d4 z;
 #pragma unroll
-    for (int r = 0; r < 4; r++) { xbuf[w][r][lane] = x0[r]; z[r] = Arow[64 + w * MT + g + 4 * r]; }
+    for (int r = 0; r < 4; r++) xbuf[w][r][lane] = x0[r];
     __syncthreads();
     // phase 2: Z1^T[w] = A1^T[w] - sum_kt L10[w][kt] X0^T[kt]
     d4 zb = zero4;
@@ -539,31 +555,43 @@ __global__ __launch_bounds__(256) void k_trsm_inv64(double* __restrict__ A, cons
     for (int kt = 0; kt < 4; kt++) {
 #pragma unroll
         for (int r = 0; r < 4; r += 2) {
-            z = __builtin_amdgcn_mfma_f64_16x16x4f64(-L10[(size_t)(w * MT + c) * ld + kt * MT + g + 4 * r],
-                                                     xbuf[kt][r][lane], z, 0, 0, 0);
-            zb = __builtin_amdgcn_mfma_f64_16x16x4f64(-L10[(size_t)(w * MT + c) * ld + kt * MT + g + 4 * (r + 1)],
-                                                      xbuf[kt][r + 1][lane], zb, 0, 0, 0);
+            z = __builtin_amdgcn_mfma_f64_16x16x4f64(l10[kt][r], xbuf[kt][r][lane], z, 0, 0, 0);
+            zb = __builtin_amdgcn_mfma_f64_16x16x4f64(l10[kt][r + 1], xbuf[kt][r + 1][lane], zb, 0, 0, 0);
         }
     }
     z += zb;
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 4; r++) { xbuf[w][r][lane] = z[r]; Arow[w * MT + g + 4 * r] = x0[r]; }
+    for (int r = 0; r < 4; r++) {
+        xbuf[w][r][lane] = z[r];
+        Arow[w * MT + g + 4 * r] = x0[r];
+    }
     __syncthreads();
     // phase 3: X1^T[w] = sum_{kt <= w} T11[w][kt] Z1^T[kt]
     d4 x1 = zero4, x1b = zero4;
-    for (int kt = 0; kt <= w; kt++) {
 #pragma unroll
-        for (int r = 0; r < 4; r += 2) {
-            x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(T11[(w * MT + c) * 64 + kt * MT + g + 4 * r], xbuf[kt][r][lane],
-                                                      x1, 0, 0, 0);
-            x1b = __builtin_amdgcn_mfma_f64_16x16x4f64(T11[(w * MT + c) * 64 + kt * MT + g + 4 * (r + 1)],
-                                                       xbuf[kt][r + 1][lane], x1b, 0, 0, 0);
+    for (int kt = 0; kt < 4; kt++)
+        if (kt <= w) {
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+                x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(t11[kt][r], xbuf[kt][r][lane], x1, 0, 0, 0);
+                x1b = __builtin_amdgcn_mfma_f64_16x16x4f64(t11[kt][r + 1], xbuf[kt][r + 1][lane], x1b, 0, 0, 0);
+            }
         }
-    }
     x1 += x1b;
 #pragma unroll
-    for (int r = 0; r < 4; r++) Arow[64 + w * MT + g + 4 * r] = x1[r];
+    for (int r = 0; r < 4; r++) {
+        Arow[64 + w * MT + g + 4 * r] = x1[r];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_trsm_inv64(double* __restrict__ A, const double* __restrict__ d64,
+                                                    int ld, int kb, const ExpertPtrs* __restrict__ bt)
+{
+    if (bt) { A = GP(bt[blockIdx.y].A); d64 = GP(bt[blockIdx.y].d64); }
+    __shared__ double xbuf[4][4][64];
+    __builtin_amdgcn_s_setprio(3);
+    strip_solve(A, d64, ld, kb, blockIdx.x, xbuf);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1123,6 +1151,7 @@ __device__ __forceinline__ unsigned helper_tasks(int q, int h)
 #undef CUGP_T
 }
 
+template <bool HANDED = false>   // HANDED: the block was written by other workgroups of this launch (agent-scope loads)
 __device__ __forceinline__ void potf2_body(double* __restrict__ Ab, int ld, double* __restrict__ d16blk,
                                            double* __restrict__ d64blk, double* __restrict__ logdet_out,
                                            double* __restrict__ sm, double* __restrict__ red)
@@ -1146,7 +1175,10 @@ __device__ __forceinline__ void potf2_body(double* __restrict__ Ab, int ld, doub
 #pragma unroll
         for (int bi = 0; bi < NMT; bi++)
 #pragma unroll
-            for (int bj = 0; bj <= bi; bj++) v[bi * (bi + 1) / 2 + bj] = Ab[(size_t)(bi * MT + r) * ld + bj * MT + c];
+            for (int bj = 0; bj <= bi; bj++) {
+                const double* src = Ab + (size_t)(bi * MT + r) * ld + bj * MT + c;
+                v[bi * (bi + 1) / 2 + bj] = HANDED ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
+            }
 #pragma unroll
         for (int q = 0; q < NLT; q++) sm[q * MTS + r * (MT + 1) + c] = v[q];
         if (t < 2 * MT) zz[t] = t == MT - 1 ? 1.0 : 0.0;    // (zz[31], never read as a double, is the arrival counter: 0)
@@ -1329,46 +1361,61 @@ __global__ __launch_bounds__(256) void k_potf2(double* __restrict__ A, int ld, i
                d64 + (size_t)kb * 8192, logdet_part + kb, sm, red);
 }
 
-// one 16x16 micro tile of A(kb+1,kb+1) -= L(kb+1,kb) L(kb+1,kb)^T, by one wave, operands straight from L2
-__device__ __forceinline__ void diag_update_wave(double* __restrict__ A, int ld, int kb, int mtile)
+// one 16x16 micro tile of A(kb+1,kb+1) -= L(kb+1,kb) L(kb+1,kb)^T by ONE workgroup, operands straight from L2: the
+// four waves take a quarter of the k range each (8 MFMAs in two chains; one wave issues an fp64 MFMA per ~138 cycles,
+// so the whole K = 128 on one wave was 32 x 138 = 4.4k cycles of the chain), partial sums through LDS, added in a fixed
+// order by wave 0, which stores the tile write-through (the consumer is another workgroup).
+__device__ __forceinline__ void diag_update_tile(double* __restrict__ A, int ld, int kb, int mtile, double* __restrict__ part)
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int bi, bj;
     tri_index(mtile, bi, bj);
     const int c = lane & 15, g = lane >> 4;
-    const int k0 = kb * TILE, i0 = (kb + 1) * TILE;
+    const int k0 = kb * TILE + 32 * w, i0 = (kb + 1) * TILE;
     const double* Li = A + (size_t)(i0 + bi * MT + c) * ld + k0 + g;
     const double* Lj = A + (size_t)(i0 + bj * MT + c) * ld + k0 + g;
     double* C = A + (size_t)(i0 + bi * MT + g) * ld + i0 + bj * MT + c;
-    // four independent accumulation chains (a dependent fp64 MFMA chain issues every ~140 cycles, independent
-    // ones every ~66), summed at the end
-    d4 acc[4];
+    double la[8], lb[8];                                // all operands in flight before the first MFMA
 #pragma unroll
-    for (int r = 0; r < 4; r++) acc[0][r] = C[(size_t)(4 * r) * ld];
+    for (int s = 0; s < 8; s++) { la[s] = -Li[4 * s]; lb[s] = Lj[4 * s]; }
+    d4 acc = (d4){0.0, 0.0, 0.0, 0.0}, acc2 = acc;
+    if (w == 0) {
 #pragma unroll
-    for (int q = 1; q < 4; q++) acc[q] = (d4){0.0, 0.0, 0.0, 0.0};
-    double la[TILE / 4], lb[TILE / 4];                 // all operands in flight before the first MFMA
+        for (int r = 0; r < 4; r++) acc[r] = C[(size_t)(4 * r) * ld];
+    }
 #pragma unroll
-    for (int s = 0; s < TILE / 4; s++) { la[s] = Li[4 * s]; lb[s] = Lj[4 * s]; }
+    for (int s = 0; s < 8; s += 2) {
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(la[s], lb[s], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(la[s + 1], lb[s + 1], acc2, 0, 0, 0);
+    }
+    acc += acc2;
+    if (w > 0) {
 #pragma unroll
-    for (int s = 0; s < TILE / 4; s++)
-        acc[s & 3] = __builtin_amdgcn_mfma_f64_16x16x4f64(-la[s], lb[s], acc[s & 3], 0, 0, 0);
-    // write-through (sc1) stores: the consumer is another workgroup (guide G16: sc1 stores need no agent release)
+        for (int r = 0; r < 4; r++) part[((w - 1) * 4 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (w == 0) {
 #pragma unroll
-    for (int r = 0; r < 4; r++)
-        __hip_atomic_store(C + (size_t)(4 * r) * ld, (acc[0][r] + acc[1][r]) + (acc[2][r] + acc[3][r]),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int r = 0; r < 4; r++) {
+            const double v = ((acc[r] + part[r * 64 + lane]) + part[(4 + r) * 64 + lane]) + part[(8 + r) * 64 + lane];
+            __hip_atomic_store(C + (size_t)(4 * r) * ld, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
 // One launch per factorisation step kb: the trailing update A22 -= L21 L21^T AND, inside it, the
-// factorisation of the NEXT diagonal block.  Workgroups 0..8 (dispatched first) update the 36 micro
-// tiles of tile (kb+1,kb+1) straight from L2; the last of them to finish (acq_rel ticket at agent
-// scope, no spinning) goes on to factor that block (potf2_body) while the other
-// workgroups of the launch run the MFMA tile products of the rest of the trailing matrix.  The
-// latency-bound diagonal block therefore never waits for a free CU slot and needs no second stream.
+// factorisation of the NEXT diagonal block.  Workgroups 0..35 (dispatched first) update one micro tile of
+// tile (kb+1,kb+1) each, straight from L2; the last of them to finish (a ticket at agent scope, no spinning)
+// goes on to factor that block (potf2_body) while the other workgroups of the launch run the MFMA tile
+// products of the rest of the trailing matrix.  The latency-bound diagonal block therefore never waits for
+// a free CU slot and needs no second stream.
+// (Round 3 also ran the panel solve inside this launch -- strips first, the diagonal workgroups and the tile
+//  products waiting on per-row counters: every tile workgroup then needs an agent-scope acquire (per-XCD L2s
+//  are not coherent) and the hand-offs cost what the kernel boundary did: 41.7 vs 43.5 us per chain-bound
+//  step, Cholesky 5.86 vs 5.52 ms at N=8192.  Not kept.)
 // ------------------------------------------------------------------------------------------
-constexpr int NDIAGWG = NLT / 4;                      // 9 workgroups x 4 waves = 36 micro tiles
+constexpr int NDIAGWG = NLT;                          // 36 workgroups, one micro tile of the next diagonal block each
 constexpr int STEP_LDS = POTF2_LDS;                   // >= GEMM_LDS (66048); two such workgroups still fit one CU
 static_assert(POTF2_LDS >= GEMM_LDS, "the fused step kernel sizes its LDS for both roles");
 
@@ -1397,21 +1444,19 @@ __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, in
         // the factorisation's serial chain: win instruction issue over the product waves sharing the SIMD
         // (this launch's own tiles and the inverse blocks running on the other streams)
         __builtin_amdgcn_s_setprio(3);
-        diag_update_wave(A, ld, kb, bid * 4 + (threadIdx.x >> 6));
-        // publish: every wave drains its (agent-scope, write-through) tile stores, workgroup barrier, then ONE
-        // lane draws the ticket with acquire-release semantics at agent scope -- the release orders this
-        // workgroup's tile before the ticket, the acquire of the last arriver orders the ticket before its reads
-        // of the other eight workgroups' tiles (HIP memory model; no reliance on how the stores are encoded)
+        diag_update_tile(A, ld, kb, bid, sm);
+        // publish: wave 0 drains its (agent-scope, write-through) tile stores, then ONE of its lanes draws the
+        // ticket (relaxed: the tile is in memory before the ticket, and the last arriver reads the tiles with
+        // agent-scope loads that bypass its L1 -- the hand-off form of the CDNA guide's Guideline 16, R1)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
         if (threadIdx.x == 0)
-            s_ticket = __hip_atomic_fetch_add(&tickets[kb], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            s_ticket = __hip_atomic_fetch_add(&tickets[kb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if (s_ticket != NDIAGWG - 1) return;           // not the last arriver
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // every wave of the last arriver (its L1/K-cache lines)
-        __syncthreads();
+        // (the last arriver reads the 36 micro tiles with agent-scope loads: potf2_body<true>, no acquire fence)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int kn = kb + 1;
-        potf2_body(A + (size_t)kn * TILE * ld + kn * TILE, ld, d16 + (size_t)kn * NMT * (MT * MT),
+        potf2_body<true>(A + (size_t)kn * TILE * ld + kn * TILE, ld, d16 + (size_t)kn * NMT * (MT * MT),
                    d64 + (size_t)kn * 8192, logdet_part + kn, sm, red);
         return;
     }
