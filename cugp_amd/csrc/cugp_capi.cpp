@@ -74,13 +74,9 @@ struct cugp_gp {
     hipStream_t aux = nullptr;      // ... except the inverse blocks that run beside the factorisation (fork/join by events):
     hipStream_t aux2 = nullptr;     // aux = the large products, aux2 = each block's own small inverse,
     hipStream_t lq = nullptr;       // lq = each block's share of K^-1 (beside the next block's bordering)
-    hipStream_t wide = nullptr;     // two-speed Cholesky: optional stream of the wide passes (TUNE_WIDE_STREAM)
-    int inv_reserve = -1;           // compute units the inverse streams (aux, aux2, lq) were created to stay off
     std::vector<hipEvent_t> bev;    // fork events, one per inverse block, + the join event (last)
     std::vector<hipEvent_t> oev;    // "block's own inverse done" events (aux2 -> aux)
     std::vector<hipEvent_t> lev;    // "block's inverse rows final" events (aux -> lq) + lq's join event (last)
-    std::vector<hipEvent_t> pnev;   // "panel p factored" (main -> wide)
-    std::vector<hipEvent_t> wev;    // "wide pass of panel p done" (wide -> main) + join (last)
     double *dX = nullptr, *dy = nullptr, *dA = nullptr, *dT = nullptr, *dU = nullptr, *dKinv = nullptr;
     double *dz = nullptr, *dalpha = nullptr, *dw = nullptr, *d16 = nullptr, *dlogdet = nullptr, *dpart = nullptr, *d64 = nullptr;
     double* dout = nullptr;
@@ -262,9 +258,9 @@ int fork_inverse_block(cugp_gp* g, int a, int b, int idx, hipStream_t from)
 // brought up to date by every earlier wide pass.  Once the window reaches the last column (small trailing
 // matrices, where the chain is the bound anyway) this IS the classic right-looking form.
 struct StepPlan {
-    int wide_k0, wide_kw;      // k tiles of the wide update issued behind this step's launch ...
+    int wide_k0, wide_kw;      // k tiles of the wide update issued at this step (after its panel solve) ...
     int wa0, wa1;              // ... over the tile columns [wa0, wa1); empty: none
-    int wcol, la0, kfirst;     // step launch: columns [kb+1, kb+1+wcol); columns >= la0 take k tiles [kfirst, kb]
+    int wcol;                  // step launch: columns [kb+1, kb+1+wcol)
 };
 
 static int tri_tiles(int n) { return n * (n + 1) / 2; }
@@ -299,7 +295,7 @@ int far_boundary(int nt, int P, int near, int p)
 
 StepPlan plan_step(int nt, int P, int near, int kb)
 {
-    StepPlan sp{0, 0, 0, 0, nt - kb - 1, 1 << 30, kb};
+    StepPlan sp{0, 0, 0, 0, nt - kb - 1};
     if (P <= 1) return sp;                                            // classic: the whole trailing matrix, k = kb
     const int p = kb / P, i = kb % P;
     const int F = far_boundary(nt, P, near, p);
@@ -310,46 +306,7 @@ StepPlan plan_step(int nt, int P, int near, int kb)
         sp.wa1 = nt;
     }
     sp.wcol = F - (kb + 1);
-    // Pairs: the near window's tiles cost a fixed ~12 us + 30.5 us per 128 of K each time they are touched, so they
-    // take their updates two steps at a time.  The even step of a pair updates only what the next step's chain
-    // needs -- columns kb+1 (solved next) and kb+2 (whose diagonal block the next launch factors) -- a launch of at
-    // most ~120 tiles that hides behind the diagonal block; the odd step gives every other near column both k tiles
-    // in one pass (la0 / kfirst of the step launch).  Panels are even, so a pair never straddles a wide pass.
-    if (g_tune[TUNE_PAIR_STEPS] != 0 && P % 2 == 0) {
-        if (i % 2 == 0 && kb + 2 < nt) {
-            sp.wcol = 2;                                              // F >= (p+1)P + 1 >= kb + 3: both are near columns
-        } else if (i % 2 == 1) {
-            sp.la0 = kb + 2;
-            sp.kfirst = kb - 1;
-        }
-    }
     return sp;
-}
-
-// The streams of the inverse blocks may be confined to all but `reserve` compute units (hipExtStreamCreateWithCUMask):
-// beside a saturated chip the factorisation's launches (panel solve, step kernel with the diagonal block inside)
-// waited 100-250 us per step for workgroup slots held by the inverse's long tiles; with a few CUs the inverse
-// never touches, the dispatcher always has room for them.  (Re)created when the tuning changes.
-int ensure_inverse_streams(cugp_gp* g)
-{
-    const int reserve = g_tune[TUNE_INVERSE_RESERVE];
-    if (g->inv_reserve == reserve) return CUGP_OK;
-    for (hipStream_t* sp : {&g->aux, &g->aux2, &g->lq}) {
-        if (*sp) { (void)hipStreamSynchronize(*sp); (void)hipStreamDestroy(*sp); *sp = nullptr; }
-    }
-    hipDeviceProp_t prop;
-    HIPCHK(hipGetDeviceProperties(&prop, g->device));
-    const int total = prop.multiProcessorCount;
-    if (reserve <= 0 || reserve > total - 8) {
-        for (hipStream_t* sp : {&g->aux, &g->aux2, &g->lq}) HIPCHK(hipStreamCreateWithFlags(sp, hipStreamNonBlocking));
-    } else {
-        const int words = (total + 31) / 32;
-        std::vector<uint32_t> mk(words, 0u);
-        for (int i = reserve; i < total; i++) mk[i / 32] |= 1u << (i % 32);
-        for (hipStream_t* sp : {&g->aux, &g->aux2, &g->lq}) HIPCHK(hipExtStreamCreateWithCUMask(sp, (uint32_t)words, mk.data()));
-    }
-    g->inv_reserve = reserve;
-    return CUGP_OK;
 }
 
 // panel width of the look-ahead factorisation for this handle (1 = classic right-looking, K = 128 per pass)
@@ -403,7 +360,6 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false)
     const int w = pipe_block(g, with_inverse);
     const int P = panel_width(g);
     const int near = g_tune[TUNE_NEAR_TILES];
-    if (w > 0 && (rc = ensure_inverse_streams(g))) return rc;
     hipStream_t m = g->stream;                              // the whole factorisation is ordered on the handle's stream
     int nblk = 0, done = 0;                                 // blocks forked so far, block rows handed over
     // Small matrices: every hand-over costs the main stream a ~11-us bubble (event record + cross-stream wait) and the
@@ -440,10 +396,9 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false)
         TimedLaunch tl(g, m, g->prof >= 2 && (kb + g->eval_seq) % PROF_STRIDE == 0);
         // (look-ahead form: plain stores -- the panel solve that follows reads the column at once, and reading
         //  freshly non-temporally stored tiles took it 50 us instead of 16)
-        launch_syrk_step(g->dA, ld, kb, nt, g->d16, g->d64, g->dlogdet, g->dtickets, m, B(g), sp.wcol, sp.la0, sp.kfirst,
+        launch_syrk_step(g->dA, ld, kb, nt, g->d16, g->d64, g->dlogdet, g->dtickets, m, B(g), sp.wcol,
                          P > 1 ? g_tune[TUNE_STEP_STREAM] : 1);
-        tl.done(0, trailing_flop(nt, kb + 1, sp.la0 < kb + 1 + sp.wcol ? sp.la0 : kb + 1 + sp.wcol, 1) +
-                       trailing_flop(nt, sp.la0, kb + 1 + sp.wcol, kb + 1 - sp.kfirst));
+        tl.done(0, trailing_flop(nt, kb + 1, kb + 1 + sp.wcol, 1));
     }
     if (mark && (rc = phase_mark(g, 2))) return rc;         // end of the factorisation on the main stream
     if (w > 0) {
@@ -668,9 +623,7 @@ int cugp_create_padded(int n, int d, int device, int npad_min, cugp_gp** out)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->aux, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->aux2, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->lq, hipStreamNonBlocking);
-    g->inv_reserve = 0;             // (ensure_inverse_streams rebuilds them CU-masked when asked to)
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->wide, hipStreamNonBlocking);
-    for (std::vector<hipEvent_t>* v : {&g->bev, &g->oev, &g->lev, &g->pnev, &g->wev}) {
+    for (std::vector<hipEvent_t>* v : {&g->bev, &g->oev, &g->lev}) {
         v->assign((size_t)g->nt + 2, nullptr);
         for (size_t i = 0; i < v->size() && e == hipSuccess; i++) e = hipEventCreateWithFlags(&(*v)[i], hipEventDisableTiming);
     }
@@ -706,7 +659,6 @@ int cugp_destroy(cugp_gp* g)
     if (g->aux) (void)hipStreamSynchronize(g->aux);
     if (g->aux2) (void)hipStreamSynchronize(g->aux2);
     if (g->lq) (void)hipStreamSynchronize(g->lq);
-    if (g->wide) (void)hipStreamSynchronize(g->wide);
     double* bufs[] = {g->dX, g->dy, g->dA, g->dT, g->dU, g->dKinv, g->dz, g->dalpha, g->dw, g->d16, g->dlogdet,
                       g->dpart, g->dout, g->d64};
     for (double* p : bufs)
@@ -721,13 +673,12 @@ int cugp_destroy(cugp_gp* g)
     for (int i = 0; i <= NPHASE; i++)
         if (g->pev[i]) (void)hipEventDestroy(g->pev[i]);
     for (hipEvent_t e : g->kev) (void)hipEventDestroy(e);
-    for (std::vector<hipEvent_t>* v : {&g->bev, &g->oev, &g->lev, &g->pnev, &g->wev})
+    for (std::vector<hipEvent_t>* v : {&g->bev, &g->oev, &g->lev})
         for (hipEvent_t e : *v)
             if (e) (void)hipEventDestroy(e);
     if (g->aux) (void)hipStreamDestroy(g->aux);
     if (g->aux2) (void)hipStreamDestroy(g->aux2);
     if (g->lq) (void)hipStreamDestroy(g->lq);
-    if (g->wide) (void)hipStreamDestroy(g->wide);
     if (g->stream) (void)hipStreamDestroy(g->stream);
     delete g;
     return CUGP_OK;
@@ -1225,12 +1176,12 @@ int cugp_set_tuning(int key, int value)
     return CUGP_OK;
 }
 
-int cugp_potrf_plan(int nt, int P, int near, int kb, int out[10])
+int cugp_potrf_plan(int nt, int P, int near, int kb, int out[5])
 {
     if (!out || nt <= 1 || kb < 0 || kb + 1 >= nt || P < 1) return CUGP_ERR_INVALID;
     const StepPlan sp = plan_step(nt, P, near, kb);
-    const int v[10] = {sp.wide_k0, sp.wide_kw, sp.wa0, sp.wa1, 0, 0, -1, sp.wcol, sp.la0, sp.kfirst};
-    for (int i = 0; i < 10; i++) out[i] = v[i];
+    const int v[5] = {sp.wide_k0, sp.wide_kw, sp.wa0, sp.wa1, sp.wcol};
+    for (int i = 0; i < 5; i++) out[i] = v[i];
     return CUGP_OK;
 }
 

@@ -7,7 +7,8 @@ namespace cugp {
 
 constexpr int TILE = 128;          // tile edge of every fp64 MFMA product and of the padded leading dimension
 
-// launch-shape thresholds, adjustable at run time for A/B tuning (cugp_set_tuning)
+// launch-shape thresholds, adjustable at run time for A/B tuning (cugp_set_tuning).  Process-wide and NOT thread-safe:
+// a bench / test hook, to be set while no other thread is inside the library (handles read it while they enqueue).
 enum { TUNE_LAUUM_WM2_MAX = 0,   // K^-1 product: use 64x64 tiles when there are at most this many 128-tiles
        TUNE_TRTRI_WM2_MAX = 1,   // inverse level: same rule
        TUNE_SYRK_REM_MAX = 2,    // trailing update: split the last partial round into 64x64 quarters when it has at most this many tiles
@@ -18,16 +19,13 @@ enum { TUNE_LAUUM_WM2_MAX = 0,   // K^-1 product: use 64x64 tiles when there are
        TUNE_GROUP_MAX_TILES = 7, // experts up to this many tiles share launches (default: all; with the inverse beside the factorisation grouping won at every size tried: 4 x 6000 rows 18.9 -> 18.3 ms, 2 x 8192 rows 23.6 -> 21.9 ms)
        TUNE_PANEL = 8,           // two-speed Cholesky: steps per panel (far columns get K = 128*this in one pass per panel); 1 = classic
        TUNE_NEAR_TILES = 9,      // ... tiles in the near window (updated every step, K = 128) at a panel's first step
-       TUNE_PAIR_STEPS = 10,     // two-speed form: the near window takes its updates two steps at a time (K = 256), see plan_step
-       TUNE_PANEL_MIN_NT = 11,   // ... only from this many tiles on (small matrices are bound by the chain alone)
-       TUNE_LAUUM_STREAM = 12,   // the K^-1 share of an inverse block on its own stream beside the next block's bordering: 0 never, 1 expert groups only, 2 always
-       TUNE_STEP_STREAM = 13,    // two-speed step kernel: non-temporal accesses to the C tiles (1) or plain ones (0)
-       TUNE_LATE_FORK_NT = 14,   // matrices of at most this many tiles hand their first nt - 2w block rows to the inverse streams in ONE block
-       TUNE_WIDE_STREAM = 15,    // wide passes on the handle's stream (0) or through a stream of their own (1: another hardware queue, same order)
-       TUNE_INVERSE_RESERVE = 16, // compute units the inverse-block streams stay off (CU-masked), so the factorisation's launches always find free slots; 0 = no mask
-       TUNE_SPLIT_REM_MAX = 17,  // uniform-K launches (block-wise K^-1 share, bordering, wide update): a last round of at most this many tiles runs as 64x64 quarters
-       TUNE_STEP_QUARTER_MAX = 18, // step kernel: launches of at most this many 64x64 workgroups run ALL their tiles as quarters (chain-bound tail)
-       TUNE_COUNT = 19 };
+       TUNE_PANEL_MIN_NT = 10,   // ... only from this many tiles on (small matrices are bound by the chain alone)
+       TUNE_LAUUM_STREAM = 11,   // the K^-1 share of an inverse block on its own stream beside the next block's bordering: 0 never, 1 expert groups only, 2 always
+       TUNE_STEP_STREAM = 12,    // two-speed step kernel: non-temporal accesses to the C tiles (1) or plain ones (0)
+       TUNE_LATE_FORK_NT = 13,   // matrices of at most this many tiles hand their first nt - 2w block rows to the inverse streams in ONE block
+       TUNE_SPLIT_REM_MAX = 14,  // uniform-K launches (block-wise K^-1 share, bordering, wide update): a last round of at most this many tiles runs as 64x64 quarters
+       TUNE_STEP_QUARTER_MAX = 15, // step kernel: launches of at most this many 64x64 workgroups run ALL their tiles as quarters (chain-bound tail)
+       TUNE_COUNT = 16 };
 extern int g_tune[TUNE_COUNT];
 
 struct HyperScalars;
@@ -70,10 +68,9 @@ void launch_trsm_inv64(double* A, const double* d64, int ld, int kb, int nt, hip
 void launch_trtri_diag(const double* A, int ld, int kb, int nblocks, const double* d64, double* T, double* U,
                        hipStream_t s, Batch bt = {});
 // trailing update of step kb fused with the factorisation of diagonal block kb+1 (tickets[kb] must be 0)
-// wcol > 0: only the tile columns [kb+1, kb+1+wcol); columns >= la0 take the k tiles [kfirst, kb] (look-ahead form)
+// wcol > 0: only the tile columns [kb+1, kb+1+wcol) (two-speed form: the near window)
 void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* d64, double* logdet_part,
-                      unsigned* tickets, hipStream_t s, Batch bt = {}, int wcol = 0, int la0 = 1 << 30, int kfirst = 0,
-                      int stream_c = 1);
+                      unsigned* tickets, hipStream_t s, Batch bt = {}, int wcol = 0, int stream_c = 1);
 // wide trailing update: tile columns [ca, cb) (rows >= column) -= L(., k tiles [k0, k0+kw)) L(.)^T; returns tiles
 int launch_syrk_wide(double* A, int ld, int nt, int k0, int kw, int ca, int cb, int rev, hipStream_t s, Batch bt = {});
 

@@ -1419,16 +1419,14 @@ constexpr int NDIAGWG = NLT;                          // 36 workgroups, one micr
 constexpr int STEP_LDS = POTF2_LDS;                   // >= GEMM_LDS (66048); two such workgroups still fit one CU
 static_assert(POTF2_LDS >= GEMM_LDS, "the fused step kernel sizes its LDS for both roles");
 
-// wcol / la0 / kfirst (look-ahead form, enqueue_potrf): the launch updates only the tile columns
-// [kb+1, kb+1+wcol) -- the rest of the current panel and the next panel -- and the far columns are brought up to
-// date once per panel by k_syrk_wide with K = P*128.  Columns >= la0 (absolute) take the k tiles [kfirst, kb]
-// instead of kb alone: the first steps of a panel leave the next panel's columns to the wide update still
-// running on them and catch up in one pass.  wcol >= the trailing size, la0 >= nt: the classic full update.
+// wcol (two-speed form, enqueue_potrf): the launch updates only the tile columns [kb+1, kb+1+wcol) -- the near
+// window -- and the far columns are brought up to date once per panel by k_syrk_wide with K = P*128.
+// wcol >= the trailing size: the classic full update.
 __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, int ld, int kb,
                                                       double* __restrict__ d16, double* __restrict__ d64,
                                                       double* __restrict__ logdet_part,
-                                                      unsigned* __restrict__ tickets, int nfull, int wcol, int la0,
-                                                      int kfirst, int stream_c, const ExpertPtrs* __restrict__ bt)
+                                                      unsigned* __restrict__ tickets, int nfull, int wcol,
+                                                      int stream_c, const ExpertPtrs* __restrict__ bt)
 {
     // batched: the EXPERT is the fast grid index, so the diagonal-block workgroups of all experts are
     // dispatched before any tile product (the serial chain of every expert starts at launch)
@@ -1475,22 +1473,20 @@ __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, in
         const int tlin = (xg < xr ? xg * (xq + 1) : xr * (xq + 1) + (xg - xr) * xq) + (x >> 3) + 1;
         trap_index((kb & 1) ? nfull + 1 - tlin : tlin, wcol, ti, tj);   // tile 0 = (kb+1,kb+1) is the diagonal one
         const int i0 = (kb + 1 + ti) * TILE, j0 = (kb + 1 + tj) * TILE;
-        const int kf = (kb + 1 + tj >= la0) ? kfirst : kb;
         d4 acc[4][4];
         if (stream_c) tile_load<true>(A + (size_t)i0 * ld + j0, ld, acc);
         else tile_load<false>(A + (size_t)i0 * ld + j0, ld, acc);
-        tile_nt<true>(A + (size_t)i0 * ld, ld, A + (size_t)j0 * ld, ld, kf * TILE, (kb + 1) * TILE, acc, (char*)sm);
+        tile_nt<true>(A + (size_t)i0 * ld, ld, A + (size_t)j0 * ld, ld, kb * TILE, (kb + 1) * TILE, acc, (char*)sm);
         if (stream_c) tile_store<true>(A + (size_t)i0 * ld + j0, ld, acc, 1.0);
         else tile_store<false>(A + (size_t)i0 * ld + j0, ld, acc, 1.0);
     } else {
         int ti, tj;
         const int y = x - nfull;
         trap_index(nfull + 1 + (y >> 2), wcol, ti, tj);
-        const int kf = (kb + 1 + tj >= la0) ? kfirst : kb;
         const int i0 = (kb + 1 + ti) * TILE + ((y >> 1) & 1) * 64, j0 = (kb + 1 + tj) * TILE + (y & 1) * 64;
         d4 acc[2][2];
         tile_load<true>(A + (size_t)i0 * ld + j0, ld, acc);
-        tile_nt<true>(A + (size_t)i0 * ld, ld, A + (size_t)j0 * ld, ld, kf * TILE, (kb + 1) * TILE, acc, (char*)sm);
+        tile_nt<true>(A + (size_t)i0 * ld, ld, A + (size_t)j0 * ld, ld, kb * TILE, (kb + 1) * TILE, acc, (char*)sm);
         tile_store<true>(A + (size_t)i0 * ld + j0, ld, acc, 1.0);
     }
 }
@@ -1817,7 +1813,7 @@ __global__ __launch_bounds__(256) void k_predict_finish(const double* __restrict
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-int g_tune[TUNE_COUNT] = {768, 1200, 384, -1, 511, 1, 1, 1 << 20, 16, 500, 0, 32, 1, 1, 12, 0, 0, 256, 1536};   // defaults chosen by interleaved A/B runs (tools/ab.py)
+int g_tune[TUNE_COUNT] = {768, 1200, 384, -1, 511, 1, 1, 1 << 20, 16, 500, 32, 1, 1, 12, 256, 1536};   // defaults chosen by interleaved A/B runs (tools/ab.py)
 
 static inline int tri_count(int n) { return n * (n + 1) / 2; }
 
@@ -1906,7 +1902,7 @@ static inline int trap_count(int m, int wcol)          // tiles (ti >= tj) of th
 }
 
 void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* d64, double* logdet_part,
-                      unsigned* tickets, hipStream_t s, Batch bt, int wcol, int la0, int kfirst, int stream_c)
+                      unsigned* tickets, hipStream_t s, Batch bt, int wcol, int stream_c)
 {
     const int m = nt - kb - 1;
     if (m <= 0) return;
@@ -1923,7 +1919,7 @@ void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* d6
     if ((long long)ntl * bt.count * 4 <= g_tune[TUNE_STEP_QUARTER_MAX]) nfull = 0;
     const unsigned nwg = NDIAGWG + nfull + 4 * (ntl - nfull);
     hipLaunchKernelGGL(k_syrk_step, bt.tab ? dim3(bt.count, nwg) : dim3(nwg), dim3(256), STEP_LDS, s, A, ld, kb, d16,
-                       d64, logdet_part, tickets, nfull, wcol, la0, kfirst, stream_c, bt.tab);
+                       d64, logdet_part, tickets, nfull, wcol, stream_c, bt.tab);
 }
 
 // tile columns [ca, cb) (rows >= column) -= L(., k0..k0+kw) L(., k0..k0+kw)^T; returns the number of tiles

@@ -190,12 +190,13 @@ int cugp_mfma_peak_tflops(int device, double *tflops);
 int cugp_bench_la(int op, int n, int device, int reps, double *ms);
 /* the same, and for ops 0 and 3 log|K| taken from the factor the timed launches produced (NaN otherwise) */
 int cugp_bench_la_check(int op, int n, int device, int reps, double *ms, double *logdet);
-int cugp_set_tuning(int key, int value);     /* launch-shape thresholds (kernels.h TUNE_*), for A/B runs */
+/* launch-shape thresholds (kernels.h TUNE_*), for A/B runs.  Process-wide and NOT thread-safe: call it only while no
+ * other thread is inside the library (handles read the values while they enqueue). */
+int cugp_set_tuning(int key, int value);
 /* the launches of step kb of the two-speed Cholesky with panels of P steps and a near window of about `near_tiles`
- * tiles (pure arithmetic, no device): out = {wide k0, wide k tiles, wide columns [a0,a1) then [b0,b1), panel whose
- * wide update the step waits for or -1, step-launch width in tile columns from kb+1, first column taking several
- * k tiles, first k tile those take}; tests/test_host_logic.py replays it: every tile sees every k exactly once */
-int cugp_potrf_plan(int nt, int P, int near_tiles, int kb, int out[10]);
+ * tiles (pure arithmetic, no device): out = {wide k0, wide k tiles, wide columns [a0,a1), step-launch width in tile
+ * columns from kb+1}; tests/test_host_logic.py replays it: every tile sees every k exactly once, ascending */
+int cugp_potrf_plan(int nt, int P, int near_tiles, int kb, int out[5]);
 
 #ifdef __cplusplus
 }

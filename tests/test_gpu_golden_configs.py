@@ -60,9 +60,12 @@ def test_dense_8192_golden(gp_mod):
     g.set_loghyperparam(c["hp"])
     ll, gr = g.loglik_grad(X, y)
     assert ll_close(ll, c["ll"]), (ll, c["ll"])
-    assert ll_close(g.compute_loglikelihood(), c["ll"])                      # LL-only path (blocked TRSV)
     cg = job("d8192_grad")
     assert grad_close(gr, cg["grad"]), (gr, cg["grad"])
+    g.close()
+    g = gp_mod.Covsum(8192, 10)                                              # fresh handle: the LL-only path (blocked
+    g.set_loghyperparam(c["hp"])                                             # TRSV), not the cached value
+    assert ll_close(g.compute_loglikelihood(X, y), c["ll"])
     g.close()
 
 
@@ -75,9 +78,10 @@ def test_config3_siproper_10000_golden(gp_mod):
     g.set_loghyperparam(c["hp"])
     ll, gr = g.loglik_grad(X, y)
     assert ll_close(ll, c["ll"]), (ll, c["ll"])
-    assert ll_close(g.compute_loglikelihood(), c["ll"])
     cg = job("s10000_grad")                                                  # 18832 s (5.2 h) of reference time
     assert grad_close(gr, cg["grad"]), (gr, cg["grad"])
+    g.set_data(X, y)                                                         # invalidates the factor: the LL-only path
+    assert ll_close(g.compute_loglikelihood(), c["ll"])                      # runs (blocked TRSV), not the cached value
     g.close()
 
 
@@ -122,3 +126,86 @@ def test_config5_si24000_16shard_golden(gp_mod, si24000, case):
     nlpp = b.get_BCM_negative_log_predprob(np.array(c["yt"]), m, v)
     assert abs(nlpp - c["nlpp"]) <= 1e-8 * max(1.0, abs(c["nlpp"]))
     b.close()
+
+
+# ------------------------------------------------------------------ round 3: where the optimiser actually goes
+@pytest.fixture(scope="module")
+def sine4160():
+    d = np.load(os.path.join(GOLDEN, "data_sine_4160.npz"))
+    return np.ascontiguousarray(d["X"]), np.ascontiguousarray(d["y"])
+
+
+@pytest.mark.parametrize("name,n", [("tail", 2048), ("tail", 4096), ("ill", 2048), ("ill", 4096)])
+def test_ill_conditioned_goldens(gp_mod, sine4160, name, n):
+    """The hyper-parameters the reference's CG run ends at (cuda_bettersinglenode_ver2/REF:3167,3183:
+    (0.882908, 0.098703, -2.971479), sigma_n^2 = 2.6e-3) on sine rows -- "tail" -- and the same amplitude and noise with
+    the dense length scale of cuda_src/main.cpp:190-193 -- "ill": cond(K) = 4.8e5 at 2048 rows, 9.7e5 at 4096 (from the
+    eigenvalues of the reference's own K, stored with the golden); the regime covkernel.cpp:509-524 guards.
+    Same tolerances as every other golden."""
+    X, y = sine4160
+    c, cg = job("%s%d_ll" % (name, n)), job("%s%d_grad" % (name, n))
+    g = gp_mod.Covsum(n, 10)
+    g.set_loghyperparam(c["hp"])
+    ll, gr = g.loglik_grad(X[:n], y[:n])
+    print("%s%d: cond(K) %.3g  LL %.12g (reference %.12g, rel. diff %.2e)" % (name, n, c["cond_K"], ll, c["ll"],
+                                                                           abs(ll - c["ll"]) / abs(c["ll"])))
+    assert ll_close(ll, c["ll"]), (ll, c["ll"])
+    assert grad_close(gr, cg["grad"]), (gr, cg["grad"])
+    g.close()
+    g = gp_mod.Covsum(n, 10)                                                 # LL-only path on a fresh handle
+    g.set_loghyperparam(c["hp"])
+    assert ll_close(g.compute_loglikelihood(X[:n], y[:n]), c["ll"])
+    g.close()
+
+
+def test_ill_conditioned_metric_size(gp_mod):
+    """siproper_9192 rows 0..8191 at the ill-conditioned hyper-parameters (3.762111, 0.098703, -2.971479): the metric
+    size, dense K, sigma_f^2 / sigma_n^2 = 470."""
+    c = job("d8192_ll_ill")
+    z = np.load(os.path.join(GOLDEN, "data_siproper_9192.npz"))
+    X, y = np.ascontiguousarray(z["X"][:8192]), np.ascontiguousarray(z["y"][:8192])
+    g = gp_mod.Covsum(8192, 10)
+    g.set_loghyperparam(c["hp"])
+    ll, gr = g.loglik_grad(X, y)
+    print("d8192 ill: LL %.12g (reference %.12g, rel. diff %.2e)" % (ll, c["ll"], abs(ll - c["ll"]) / abs(c["ll"])))
+    assert ll_close(ll, c["ll"]), (ll, c["ll"])
+    cg = job("d8192_grad_ill")
+    assert grad_close(gr, cg["grad"]), (gr, cg["grad"])
+    g.close()
+
+
+@pytest.mark.parametrize("name", ["si24000_bcm16_tail", "si24000_bcm16_ill"])
+def test_config5_at_the_cg_end_point(gp_mod, si24000, name):
+    """Config 5 (16 x 1500 rows) at the hyper-parameters the reference's CG run ends at, and at the ill-conditioned ones."""
+    X, y = si24000
+    c = job(name)
+    b = gp_mod.BCM.split(X, y, 16)
+    b.set_BCM_log_hyperparam(c["hp"])
+    ll, gr, per = b.loglik_grad()
+    assert ll_close(ll, c["ll"]), (ll, c["ll"])
+    assert grad_close(gr, c["grad"]), (gr, c["grad"])
+    assert np.allclose(per, c["ll_per_expert_6dp"], rtol=0, atol=6e-7 * max(1.0, np.max(np.abs(per)) * 1e-6))
+    b.close()
+
+
+def test_cg_trajectory_sine_1024(gp_mod, sine4160):
+    """Covsum::cg_solve (covkernel.cpp:405-647) on sine rows 0..1023 from the dense starting point against the
+    reference's trace (75 probes; 264 s of reference time).  This run walks into sigma_f -> 0 (log sigma_f < -15: K
+    is sigma_n^2 I to rounding) where the objective is constant to 1e-14 and the (l, sigma_f) components of the
+    gradient are rounding noise: the probes are compared one for one while the objective still moves (the first 39
+    here), afterwards only what is determined -- the noise hyper-parameter at every probe and the final objective."""
+    X, y = sine4160
+    c = job("cg_sine1024")
+    g = gp_mod.Covsum(1024, 10)
+    g.set_loghyperparam(c["hp0"])
+    tr = g.cg_solve(X[:1024], y[:1024])
+    final = g.get_loghyperparam()
+    probes = np.array([p[1:] for p in c["please_see"] if p[0] in (1, 2)])
+    assert tr.shape[0] == probes.shape[0] + 1, (tr.shape, probes.shape)
+    err = np.abs(tr[1:, :3] - probes) / np.maximum(1.0, np.abs(probes))
+    moving = np.abs(tr[1:, 3] + c["final_ll"]) > 1e-9 * abs(c["final_ll"])     # trace column 3 is -LL
+    assert moving.sum() >= 35 and np.all(err[moving] <= 5e-5), (moving.sum(), np.max(err[moving]))
+    assert np.all(err[:, 2] <= 1e-5), np.max(err[:, 2])
+    assert abs(final[2] - c["final_hp"][2]) <= 1e-6
+    assert abs(g.compute_loglikelihood() - c["final_ll"]) <= 1e-8 * abs(c["final_ll"])
+    g.close()

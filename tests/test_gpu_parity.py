@@ -498,26 +498,59 @@ def test_config3_ragged_10000_cg(gp_mod):
     assert np.max(np.abs(L[rows] @ L.T - K[rows])) <= 1e-11 * np.max(np.abs(K))
 
 
-@pytest.mark.parametrize("K,rows", [(4, 6000), (16, 1500)])
-def test_config45_bcm_shapes(gp_mod, K, rows):
-    """si6000 x 4 experts and si24000 16-shard shapes on one GPU: experts run concurrently on their own
-    streams; the sums equal the per-expert evaluations done one at a time (bit for bit)."""
-    X, y = synth(K * rows, seed=24000 + K)
+# ------------------------------------------------------------------ round 3
+@pytest.mark.parametrize("n", [1100, 4200])
+def test_gradient_continues_from_a_valid_factor(gp_mod, oracle, n):
+    """compute_loglikelihood() then compute_gradient_loghyperparam() (the reference's canonical pair,
+    cpp_serial_gp/covkernel.cpp:118-129 then :162-263, and every gradient probe of the evaluation-sparing CG): the
+    gradient continues from the factor the value call left -- on a padded multi-tile handle (1100 rows: 9 tiles, 52
+    rows of identity padding; 4200 rows: 33 tiles, two-speed schedule, doubling levels) it must give what one
+    loglik_grad() gives, to rounding."""
+    X, y = synth(n, seed=n)
     hp = [np.log(3.0), 0.0, np.log(0.1)]
-    b = gp_mod.BCM.split(X, y, K)
+    a = gp_mod.Covsum(n, 10)
+    a.set_loghyperparam(hp)
+    ll0, g0 = a.loglik_grad(X, y)
+    Ki0, al0 = a.get_K_inverse(), a.get_alpha()
+    a.close()
+    b = gp_mod.Covsum(n, 10)
+    b.set_loghyperparam(hp)
+    ll1 = b.compute_loglikelihood(X, y)                       # factor only
+    g1 = b.compute_gradient_loghyperparam()                   # continues: inverse, alpha, traces
+    Ki1, al1 = b.get_K_inverse(), b.get_alpha()
+    assert abs(ll1 - ll0) <= 1e-11 * abs(ll0)
+    assert np.all(np.abs(g1 - g0) <= 1e-9 * np.abs(g0) + 1e-12 * np.max(np.abs(g0)))
+    assert np.max(np.abs(Ki1 - Ki0)) <= 1e-11 * np.max(np.abs(Ki0))
+    assert np.max(np.abs(al1 - al0)) <= 1e-11 * np.max(np.abs(al0))
+    if n <= 1100:                                             # ... and what the oracle gives
+        llo, go = oracle.loglik_grad(X, y, hp)
+        assert abs(ll1 - llo) <= 1e-8 * max(1.0, abs(llo))
+        assert np.all(np.abs(g1 - go) <= 1e-6 * np.abs(go) + 1e-9 * np.max(np.abs(go)))
+    b.close()
+
+
+def test_gradient_continues_on_a_bcm_expert_view(gp_mod, oracle):
+    """The same pair on a borrowed BCM expert (2300 rows in 3 experts: 766 + 766 + 768 rows, created with the common
+    padded size of 768 = 6 tiles): value first, then the gradient from the valid factor, against the oracle on that
+    expert's rows."""
+    X, y = synth(2300, seed=77)
+    hp = [np.log(2.0), 0.1, np.log(0.2)]
+    b = gp_mod.BCM.split(X, y, 3)
     b.set_BCM_log_hyperparam(hp)
-    ll, gr, per = b.loglik_grad()
-    acc_ll, acc_g = 0.0, np.zeros(3)
-    for k in (0, K - 1):
-        g = gp_mod.Covsum(rows, 10)
-        g.set_loghyperparam(hp)
-        l, gg = g.loglik_grad(X[k * rows:(k + 1) * rows], y[k * rows:(k + 1) * rows])
-        # (same kernels; the inverse may be built in different block orders -> last-bit differences at most)
-        assert abs(l - per[k]) <= 1e-11 * abs(l)
-        g.close()
+    rows = b.rows
+    lo = 0
+    for k in range(3):
+        e = b.expert(k)
+        Xk, yk = X[lo:lo + rows[k]], y[lo:lo + rows[k]]
+        lo += rows[k]
+        ll = e.compute_loglikelihood()
+        gr = e.compute_gradient_loghyperparam()
+        llo, go = oracle.loglik_grad(Xk, yk, hp)
+        assert abs(ll - llo) <= 1e-8 * max(1.0, abs(llo)), (k, ll, llo)
+        assert np.all(np.abs(gr - go) <= 1e-6 * np.abs(go) + 1e-9 * np.max(np.abs(go))), (k, gr, go)
+    ll, gr, per = b.loglik_grad()                             # the group evaluation afterwards still agrees
     assert np.isfinite(ll) and abs(ll - np.sum(per)) <= 1e-9 * abs(ll)
-    m, v = b.compute_BCM_test_means_and_var(X[:7] + 0.01)
-    assert np.all(np.isfinite(m)) and np.all(v > 0) and np.all(v < np.exp(2 * hp[1]) + np.exp(2 * hp[2]))
+    b.close()
 
 
 # ------------------------------------------------------------------ rows closed in round 2

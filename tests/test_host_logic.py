@@ -155,7 +155,6 @@ def test_row_partition_matches_reference(oracle, si128):
 # ---------------------------------------------------------------------------------------------
 # two-speed Cholesky: the launch schedule (cugp_potrf_plan = the arithmetic enqueue_potrf uses)
 # ---------------------------------------------------------------------------------------------
-PAIR_STEPS_DEFAULT = 0
 
 
 def _replay_potrf_plan(nt, P, near):
@@ -166,13 +165,13 @@ def _replay_potrf_plan(nt, P, near):
     applied = {(i, j): [] for j in range(nt) for i in range(j, nt)}
     last_far = 0
     for kb in range(nt - 1):
-        out = (C.c_int * 10)()
+        out = (C.c_int * 5)()
         assert lib.cugp_potrf_plan(nt, P, near, kb, out) == 0
-        k0, kw, a0, a1, b0, b1, wait, wcol, la0, kfirst = list(out)
+        k0, kw, a0, a1, wcol = list(out)
         # panel solve of column kb: every tile of the column is up to date
         for i in range(kb, nt):
             assert applied[(i, kb)] == list(range(kb)), (nt, P, near, kb, i, applied[(i, kb)])
-        assert wcol >= 1 and wait == -1 and b1 <= b0
+        assert wcol >= 1
         far = kb + 1 + wcol                                          # first column outside this launch's window
         assert far <= nt
         if a1 > a0:
@@ -187,9 +186,8 @@ def _replay_potrf_plan(nt, P, near):
         else:
             assert far == nt or kb % P != P - 1
         for j in range(kb + 1, far):
-            ks = list(range(kfirst, kb + 1)) if j >= la0 else [kb]
             for i in range(j, nt):
-                applied[(i, j)] += ks
+                applied[(i, j)] += [kb]
         # the diagonal block factored inside this launch
         assert applied[(kb + 1, kb + 1)] == list(range(kb + 1)), (nt, P, near, kb, applied[(kb + 1, kb + 1)])
     for (i, j), ks in applied.items():
@@ -197,16 +195,10 @@ def _replay_potrf_plan(nt, P, near):
 
 
 def test_potrf_plan_covers_every_update_exactly_once_in_order():
-    lib = capi.lib()
-    try:
-        for pairs in (0, 1):                                 # TUNE_PAIR_STEPS: near window updated every / every other step
-            assert lib.cugp_set_tuning(10, pairs) == 0
-            for P in (1, 2, 3, 4, 5, 8, 16, 32):             # 16 / 500 is the shipped default
-                for near in (1, 40, 300, 500, 700, 5000):
-                    for nt in list(range(2, 30)) + [40, 63, 64, 79]:
-                        _replay_potrf_plan(nt, P, near)
-    finally:
-        assert lib.cugp_set_tuning(10, PAIR_STEPS_DEFAULT) == 0
+    for P in (1, 2, 3, 4, 5, 8, 16, 32):                     # 16 / 500 is the shipped default
+        for near in (1, 40, 300, 500, 700, 5000):
+            for nt in list(range(2, 30)) + [40, 63, 64, 79]:
+                _replay_potrf_plan(nt, P, near)
 
 
 def test_cg_sparing_takes_the_default_trajectory_with_fewer_gradients(oracle, si128):
