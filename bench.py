@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- GP log-lik+grad evaluations/s at N=8192, D=10 (fp64) on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--steps K] [--warmup W]                    (one GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+           --master-port P bench.py --gpus N --steps K --warmup W   (N > 1: one rank per GPU; under torchrun
+                                                                  --gpus defaults to WORLD_SIZE)
 
 One "step" = one evaluation of the hot path at a fresh hyper-parameter vector: SE-kernel build,
 blocked Cholesky, triangular inverse, K^-1, log-likelihood and its 3 gradients (the pair the
@@ -13,8 +14,14 @@ With N ranks every rank owns one N=8192 expert (BCM sharding: experts are indepe
 and the per-evaluation exchange is one all-reduce of K x 4 doubles over RCCL.
 
 Rank 0 prints ONE JSON line; besides the driver's contract it carries
-  roofline        the Cholesky trailing update (fp64 MFMA SYRK), HIP-event timed per launch in the timed region
+  roofline        the MFMA kernel with the largest share of kernel time in the timed region (HIP events around its
+                  launches on the stream they run on; algorithmic flop / duration against the fp64 MFMA peak)
+  roofline_kernels  the same record for every timed kernel, named as rocprofv3 names them
+  roofline_trailing_update  k_syrk_step + k_syrk_wide together: the N^3/3 flop of the factorisation's trailing update
   roofline_kbuild the SE-kernel build: bytes written / HIP-event time of its launch against the HBM peak
+  predict         1000 test points against the N=8192 model (covkernel.cpp:277-323), ms per call
+  bcm_si24000_16shard, bcm_si6000_4chunk   BASELINE configs 5 and 4 as strong-scaling sub-runs in the same process
+                  group (16 x 1500 and 4 x 6000 rows, expert k on rank k mod N): ms per BCM evaluation, evals/s
   cpu_baseline    the serial CPU restatement of cpp_serial_gp (oracle/, 1 thread) on a bounded sample, next to
                   what the reference's own code, compiled unmodified, needed for the full-size evaluation
 """
@@ -36,7 +43,17 @@ N_METRIC, D_METRIC = 8192, 10
 HP0 = np.array([np.log(3.0), 0.0, np.log(0.1)])      # non-degenerate point: K is dense, cond ~ 1e3
 MFMA_F64_PEAK_TFLOPS = 78.6                          # MI355X dense fp64 matrix peak (spec)
 HBM_PEAK_GBS = 8000.0                                # MI355X HBM3E (MI355X_MICROARCH.md)
-PMC_SUMMARY = "profiles/r02_pmc_summary.json"        # rocprofv3 --pmc passes of this command (tools/pmc.sh)
+PMC_SUMMARY = "profiles/r03_pmc_summary.json"        # rocprofv3 --pmc passes of this command (tools/pmc.sh)
+# kernels timed by the library at profiling level 2 (cugp_get_kernel_stats_kind): name as rocprofv3 prints it, what it
+# is, and one launch in how many is timed
+KINDS = {0: ("k_syrk_step", "Cholesky near-window trailing update + next diagonal block, K=128 per launch", 8),
+         1: ("k_syrk_wide", "Cholesky far trailing update, K=128*panel per launch", 1),
+         2: ("k_trtri_border<4>", "bordering steps of L^-1, 128x128 output tiles", 2),
+         3: ("k_trtri_border<2>", "bordering steps of L^-1, 64x64 output tiles", 2),
+         4: ("k_lauum<4>", "shares of K^-1 = L^-T L^-1, 128x128 output tiles", 2),
+         5: ("k_lauum<2>", "shares of K^-1, 64x64 output tiles", 2),
+         6: ("k_trtri_level<4>", "doubling inside a block of inverse rows, 128x128 output tiles", 8),
+         7: ("k_trtri_level<2>", "doubling inside a block of inverse rows, 64x64 output tiles", 8)}
 
 
 def synth(n, d, seed):
@@ -80,7 +97,7 @@ def cpu_baseline(n_sample, n_full, d):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=0, help="ranks = GPUs (default: WORLD_SIZE under torchrun, else 1)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", dest="n", type=int, default=N_METRIC, help="rows per expert (metric config: 8192)")
@@ -91,6 +108,7 @@ def main():
                          "(e.g. --experts-total 16 --rows 1500 = the si24000 16-shard shape); value = BCM objective "
                          "evaluations/s (all experts + all-reduce per evaluation)")
     ap.add_argument("--cpu-sample", type=int, default=2560, help="rows for the CPU baseline (0 = skip)")
+    ap.add_argument("--sub-steps", type=int, default=10, help="timed evaluations of each BCM sub-run (configs 4, 5); 0 = skip")
     ap.add_argument("--overlap", type=int, default=1, help="0: build the inverse after the factorisation on one stream "
                     "(every kernel has the chip to itself: the per-kernel roofline of the whole run is the isolated one "
                     "and no extra pass is made)")
@@ -108,6 +126,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus <= 0:
+        args.gpus = world
     if world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d (WORLD_SIZE is %d)"
                          % (args.gpus, args.gpus, world))
@@ -163,8 +183,8 @@ def main():
         step(i)
     if timed_launches:
         first_e = next(iter(bcm.local.values()))
-        first_e.kernel_stats(reset=True, kind=0)
-        first_e.kernel_stats(reset=True, kind=1)
+        for kd in KINDS:
+            first_e.kernel_stats(reset=True, kind=kd)
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -177,26 +197,75 @@ def main():
     dt = float(tmax.item())
 
     first = next(iter(bcm.local.values()), None)      # None: a rank that owns no expert
-    ks = first.kernel_stats(kind=0) if timed_launches else {"launches": 0}
-    kw = first.kernel_stats(kind=1) if timed_launches else {"launches": 0}
+    empty = {"launches": 0, "sum_ms": 0.0, "flop": 0.0}
+    kst = {kd: (first.kernel_stats(kind=kd) if timed_launches else dict(empty)) for kd in KINDS}
     ph = first.phase_ms() if timed_launches else {"potrf": float("nan"), "kbuild": float("nan")}
     npad = -(-args.n // 128) * 128
 
-    # Outside the timed region: the same kernel with the chip to itself.  In the timed region the inverse blocks
-    # run beside the factorisation on other streams, so a trailing-update launch shares the CUs and its duration
-    # is not a statement about the kernel alone; eight more evaluations with the overlap off give that number.
-    iso = iso_ph = iso_w = None
-    if rank == 0 and len(bcm.local) == 1 and args.overlap:
+    # Outside the timed region: the same kernels with the chip to themselves.  In the timed region the inverse blocks
+    # run beside the factorisation on other streams, so a launch shares the CUs and its duration is not a statement
+    # about the kernel alone; eight more evaluations with the overlap off give that number.
+    iso = iso_ph = None
+    if rank == 0 and len(bcm.local) == 1 and args.overlap and timed_launches:
         first.set_overlap(False)
-        first.kernel_stats(reset=True, kind=0)
-        first.kernel_stats(reset=True, kind=1)
-        for i in range(8):                        # level-2 profiling times every 8th launch, rotating
+        for kd in KINDS:
+            first.kernel_stats(reset=True, kind=kd)
+        for i in range(8):                        # level-2 profiling times every 8th step launch, rotating
             first.set_loghyperparam(HP0 + 1e-3 * ((i % 7) - 3))
             first.loglik_grad()
-        iso = first.kernel_stats(kind=0)
-        iso_w = first.kernel_stats(kind=1)
+        iso = {kd: first.kernel_stats(kind=kd) for kd in KINDS}
         iso_ph = first.phase_ms()
         first.set_overlap(True)
+
+    # prediction (covkernel.cpp:277-323): 1000 test points against the resident model, factor and inverse valid
+    predict = None
+    if rank == 0 and world == 1 and len(bcm.local) == 1 and not strong:
+        Xt = synth(1000, args.d, 99)[0]
+        first.set_profiling(0)
+        first.set_loghyperparam(HP0)
+        first.loglik_grad()
+        first.compute_test_means_and_variances(None, None, Xt)
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        for _ in range(5):
+            first.compute_test_means_and_variances(None, None, Xt)
+        torch.cuda.synchronize()
+        pms = 1e3 * (time.perf_counter() - tp) / 5
+        predict = {"what": "predictive mean + variance of 1000 test points against the N=%d model (host arrays in, "
+                           "host arrays out; factor and inverse resident)" % args.n, "ntest": 1000, "ms": pms,
+                   "points_per_s": 1000.0 / (pms * 1e-3)}
+
+    # BASELINE configs 5 and 4 as strong-scaling sub-runs in the same process group: the si24000 16-shard and the
+    # si6000 4-chunk shapes (synthetic rows), expert k on rank k mod N (cuda_scalingdist/cg_solver.cpp:93,166), one
+    # all-reduce of K x 4 doubles per evaluation -- so that a 1/2/4/8-GPU run yields the north_star's scaling curve
+    bcm.close()
+    subs = {}
+    if args.sub_steps > 0 and not strong and args.n == N_METRIC and args.experts_per_gpu == 1:
+        for name, (Ks, rows) in (("bcm_si24000_16shard", (16, 1500)), ("bcm_si6000_4chunk", (4, 6000))):
+            ex = [synth(rows, args.d, 24000 + 100 * Ks + k) if k % world == rank else None for k in range(Ks)]
+            sb = ShardedBCM(ex, rank=rank, world=world, device=local_rank,
+                            comm_device=torch.device("cuda", local_rank) if args.rehearse_rccl else None)
+            if args.rehearse_rccl and world == 1:
+                sb._allreduce = lambda t: (dist.all_reduce(t, op=dist.ReduceOp.SUM), t)[1]
+            for i in range(2):
+                sb.set_loghyper(HP0 + 1e-3 * i)
+                sb.loglik_grad()
+            fence()
+            ts = time.perf_counter()
+            for i in range(args.sub_steps):
+                sb.set_loghyper(HP0 + 1e-3 * ((i % 7) - 3))
+                sll, sg, _ = sb.loglik_grad()
+            fence()
+            sdt = time.perf_counter() - ts
+            tm = torch.tensor([sdt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            if collective:
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+            sdt = float(tm.item())
+            subs[name] = {"experts": Ks, "rows_per_expert": rows, "experts_per_gpu": -(-Ks // world), "n_gpus": world,
+                          "steps": args.sub_steps, "ms_per_eval": 1e3 * sdt / args.sub_steps,
+                          "evals_per_s": args.sub_steps / sdt, "scaling": "strong", "ll_last": sll,
+                          "eval_tflops_n3": Ks * float(rows) ** 3 / (sdt / args.sub_steps) / 1e12}
+            sb.close()
 
     if rank == 0:
         evals = args.steps * (1 if strong else K)
@@ -217,6 +286,9 @@ def main():
             "phase_ms_last": {k: round(v, 4) for k, v in ph.items()},
             "ll_last": ll, "grad_last": [float(v) for v in g],
         }
+        if predict:
+            out["predict"] = predict
+        out.update(subs)
         # HBM bytes per launch from the rocprofv3 --pmc passes of this same command, committed under profiles/
         # (tools/pmc.sh, tools/pmc_summary.py: 2 x FETCH_SIZE + WRITE_SIZE per launch; counters cannot be read
         # in-process, so the figure is a committed measurement and says where it comes from)
@@ -227,51 +299,52 @@ def main():
         except Exception:
             pmc = {}
 
-        def roof(name, what, st, iso_st):
+        def roof(kd, st, iso_st):
+            name, what, every = KINDS[kd]
             ach = st["flop"] / (st["sum_ms"] * 1e-3) / 1e12
-            r = {"kernel": what, "bound": "mfma", "achieved": ach, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                 "frac": ach / MFMA_F64_PEAK_TFLOPS,
+            r = {"kernel": "%s (%s; fp64 MFMA 16x16x4)" % (name, what), "bound": "mfma", "achieved": ach,
+                 "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F64_PEAK_TFLOPS,
                  "traffic": pmc.get(name, {}).get("hbm_bytes_per_launch"),
                  "traffic_source": PMC_SUMMARY if name in pmc else None,
-                 "launches": int(st["launches"]), "avg_launch_us": 1e3 * st["sum_ms"] / st["launches"],
-                 "algorithmic_flop_per_launch": st["flop"] / st["launches"]}
+                 "mfma_busy_frac_pmc": pmc.get(name, {}).get("mfma_busy_frac"),
+                 "launches_timed": int(st["launches"]), "timed_one_launch_in": every,
+                 "avg_launch_us": 1e3 * st["sum_ms"] / st["launches"],
+                 "algorithmic_flop_per_launch": st["flop"] / st["launches"],
+                 "est_ms_per_eval": every * st["sum_ms"] / args.steps}
             if iso_st and iso_st["launches"] > 0:
                 ia = iso_st["flop"] / (iso_st["sum_ms"] * 1e-3) / 1e12
                 r.update({"isolated_achieved": ia, "isolated_frac": ia / MFMA_F64_PEAK_TFLOPS,
-                          "isolated_avg_launch_us": 1e3 * iso_st["sum_ms"] / iso_st["launches"],
-                          "note": "achieved/frac: timed region, where a launch shares the CUs with the inverse blocks "
-                                  "on the other streams; isolated_*: same kernel, overlap off"})
+                          "isolated_avg_launch_us": 1e3 * iso_st["sum_ms"] / iso_st["launches"]})
             return r
 
-        # the dominant kernel of the factorisation: the wide trailing update when the two-speed schedule is on
-        # (most of the flop), else the step kernel (all of it)
-        wide_dominant = kw["launches"] > 0 and kw["flop"] * 8 > ks.get("flop", 0.0)   # step launches are sampled 1 in 8
-        if ks["launches"] > 0:
-            step = roof("k_syrk_step", "k_syrk_step (Cholesky trailing update + next diagonal block, fp64 MFMA 16x16x4, "
-                        "K=128 per launch)", ks, iso)
-            if wide_dominant:
-                out["roofline"] = roof("k_syrk_wide", "k_syrk_wide (Cholesky far trailing update, fp64 MFMA 16x16x4, "
-                                       "K=128*panel per launch)", kw, iso_w if iso is not None else None)
-                out["roofline_step"] = step
-                # the two kernels of the trailing update together: their flop over the sum of their durations (every
-                # wide launch is timed, one step launch in 8: scale the step sample up)
+        recs = {KINDS[kd][0]: roof(kd, kst[kd], iso[kd] if iso else None) for kd in KINDS if kst[kd]["launches"] > 0}
+        if recs:
+            tot = sum(r["est_ms_per_eval"] for r in recs.values())
+            for r in recs.values():
+                r["share_of_timed_kernel_time"] = r["est_ms_per_eval"] / tot
+            dom = max(recs, key=lambda k: recs[k]["est_ms_per_eval"])
+            out["roofline"] = dict(recs[dom])
+            out["roofline"]["dominant_by"] = ("largest share of the MFMA kernels' time in the timed region "
+                                              "(est_ms_per_eval; rocprofv3 --kernel-trace --stats of this command: "
+                                              "profiles/r03_bench_n8192_kernel_stats.csv)")
+            out["roofline"]["note"] = ("achieved/frac: timed region, where a launch shares the CUs with kernels on the "
+                                       "other streams; isolated_*: same kernel, overlap off")
+            out["roofline"]["whole_evaluation_frac"] = out["eval_tflops_n3"] / MFMA_F64_PEAK_TFLOPS
+            out["roofline_kernels"] = recs
+            ks, kw = kst[0], kst[1]
+            if ks["launches"] > 0 and kw["launches"] > 0:
+                # the two kernels of the factorisation's trailing update together: their flop over the sum of their
+                # durations (every wide launch is timed, one step launch in 8: scale the step sample up)
                 fl = kw["flop"] + 8.0 * ks["flop"]
                 ms = kw["sum_ms"] + 8.0 * ks["sum_ms"]
                 tu = {"what": "k_syrk_wide + k_syrk_step together (N^3/3 flop of the factorisation)",
                       "achieved": fl / (ms * 1e-3) / 1e12, "unit": "TFLOP/s", "peak": MFMA_F64_PEAK_TFLOPS,
                       "wide_share_of_flop": kw["flop"] / fl}
                 tu["frac"] = tu["achieved"] / MFMA_F64_PEAK_TFLOPS
-                if iso is not None and iso["launches"] > 0 and iso_w["launches"] > 0:
-                    ia = (iso_w["flop"] + 8.0 * iso["flop"]) / ((iso_w["sum_ms"] + 8.0 * iso["sum_ms"]) * 1e-3) / 1e12
+                if iso and iso[0]["launches"] > 0 and iso[1]["launches"] > 0:
+                    ia = (iso[1]["flop"] + 8.0 * iso[0]["flop"]) / ((iso[1]["sum_ms"] + 8.0 * iso[0]["sum_ms"]) * 1e-3) / 1e12
                     tu["isolated_achieved"], tu["isolated_frac"] = ia, ia / MFMA_F64_PEAK_TFLOPS
                 out["roofline_trailing_update"] = tu
-                out["roofline"]["share_of_factorisation_flop"] = tu["wide_share_of_flop"]
-                out["roofline"]["dominant_by"] = ("flop of the factorisation; by time it is k_syrk_step, whose launches "
-                                                  "carry the latency-bound diagonal block: see roofline_step and "
-                                                  "roofline_trailing_update")
-            else:
-                out["roofline"] = step
-            out["roofline"]["whole_evaluation_frac"] = out["eval_tflops_n3"] / MFMA_F64_PEAK_TFLOPS
         if timed_launches and ph["kbuild"] == ph["kbuild"]:
             # SE-kernel build: lower 64x64 tiles of K written once (+ X read), HIP events around its launch
             nbytes = (npad // 64) * (npad // 64 + 1) // 2 * 64 * 64 * 8 + args.n * args.d * 8
@@ -286,7 +359,6 @@ def main():
             out["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, args.n), args.n, args.d)
         print(json.dumps(out), flush=True)
 
-    bcm.close()
     if collective:
         dist.barrier()
         dist.destroy_process_group()

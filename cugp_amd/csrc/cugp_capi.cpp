@@ -49,6 +49,9 @@ constexpr int NPHASE = 6;
 constexpr int MAX_KEV = 4096;   // per-launch event pairs kept between resets
 constexpr int GRAPH_MAX_TILES = 24;   // evaluations up to 3072 rows are replayed as captured graphs
 constexpr int PROF_STRIDE = 8;  // profiling level 2 times every 8th trailing-update launch, rotating
+// kinds of timed launches (cugp_get_kernel_stats_kind): the kernels as rocprofv3 names them
+enum { KIND_STEP = 0, KIND_WIDE = 1, KIND_BORDER4 = 2, KIND_BORDER2 = 3, KIND_LAUUM4 = 4, KIND_LAUUM2 = 5,
+       KIND_LEVEL4 = 6, KIND_LEVEL2 = 7, KIND_COUNT = 8 };
 
 // One hardware queue per stream up to 16 (the runtime default is 4): the experts of a BCM on one device each
 // drive their own stream, and 16 experts on 4 queues serialise (5.8 ms vs 4.6 ms per evaluation of 16 x 1500
@@ -106,13 +109,13 @@ struct cugp_gp {
     int prof = 0;
     hipEvent_t pev[NPHASE + 1] = {};
     bool pev_valid = false;
-    std::vector<hipEvent_t> kev;   // start/stop pairs around trailing updates
-    std::vector<int> kev_kind;     // per pair: 0 = k_syrk_step, 1 = k_syrk_wide
+    std::vector<hipEvent_t> kev;   // start/stop pairs around MFMA launches (profiling level 2)
+    std::vector<int> kev_kind;     // per pair: KIND_* below
     std::vector<double> kev_flopv; // per pair: algorithmic flop of the launch
     int kev_used = 0;
     unsigned eval_seq = 0;         // factorisations enqueued so far (rotates the launches that get timed)
-    double kst_ms[2] = {0, 0}, kst_flop[2] = {0, 0};   // folded sums per kernel kind
-    long long kst_launches[2] = {0, 0};
+    double kst_ms[8] = {}, kst_flop[8] = {};           // folded sums per kernel kind
+    long long kst_launches[8] = {};
 };
 
 namespace {
@@ -181,6 +184,61 @@ int pipe_block(const cugp_gp* g, bool with_inverse)
     return w >= g->nt ? 0 : w;
 }
 
+// one timed launch (profiling level 2): event pair + bookkeeping
+struct TimedLaunch {
+    cugp_gp* g; hipStream_t s; bool on;
+    TimedLaunch(cugp_gp* g_, hipStream_t s_, bool want) : g(g_), s(s_), on(want && g_->kev_used + 2 <= (int)g_->kev.size())
+    {
+        if (on && hipEventRecord(g->kev[g->kev_used], s) != hipSuccess) on = false;
+    }
+    void done(int kind, double flop)
+    {
+        if (!on) return;
+        if (hipEventRecord(g->kev[g->kev_used + 1], s) != hipSuccess) return;
+        g->kev_kind[g->kev_used / 2] = kind;
+        g->kev_flopv[g->kev_used / 2] = flop;
+        g->kev_used += 2;
+    }
+};
+
+// algorithmic flop of the inverse's tile products (multiply + add; a k tile that is triangular counts half).
+// border step 1, one chunk: Wt(tj < c1, ti in [ra, ra+rw)) (+)= sum_{k in [max(tj,c0), c1)} U[tj][k] L[ti][k]
+double border1_flop(int rw, int c0, int c1)
+{
+    double kt = 0;
+    for (int tj = 0; tj < c1; tj++) kt += (c1 - (tj > c0 ? tj : c0)) - (tj >= c0 ? 0.5 : 0.0);   // U[tj][tj] is triangular
+    return kt * rw * 2.0 * TILE * TILE * TILE;
+}
+// border step 2: T(ti in [a, a+w), tj < a) = -sum_{k in [a, ti]} T[ti][k] Wt[tj][k]   (T[ti][ti] triangular)
+double border2_flop(int a, int w)
+{
+    double kt = 0;
+    for (int i = 0; i < w; i++) kt += i + 0.5;
+    return kt * a * 2.0 * TILE * TILE * TILE;
+}
+// K^-1 share of inverse rows [a, a+w): Kinv(ti,tj) (+)= sum_{k in [max(ti,a), a+w)} U[ti][k] U[tj][k]^T, tj <= ti < a+w
+double lauum_flop(int a, int w)
+{
+    double kt = 0;
+    for (int ti = 0; ti < a + w; ti++) {
+        const double k = (a + w) - (ti > a ? ti : a);
+        kt += (ti + 1) * k - (ti >= a ? 0.5 * (ti + 1) : 0.0) - (ti >= a ? 0.5 * k : 0.0);   // triangular k tile; diagonal output tile
+    }
+    return kt * 2.0 * TILE * TILE * TILE;
+}
+// one level of recursive doubling over nt tiles, blocks of s: both steps move |A| x |B| tiles with k ranges up to s
+double level_flop(int nt, int s, int step)
+{
+    double kt = 0;
+    for (int a0 = 0; a0 + s < nt; a0 += 2 * s) {
+        int sb = nt - (a0 + s);
+        if (sb > s) sb = s;
+        if (step == 1) for (int ja = 0; ja < s; ja++) kt += (s - ja - 0.5) * sb;       // k from tj to the end of A
+        else for (int ib = 0; ib < sb; ib++) kt += (ib + 0.5) * s;                     // k from b0 to ti
+    }
+    return kt * 2.0 * TILE * TILE * TILE;
+}
+
 // Inverse quantities of block rows [a, b): T and U = T^T (diagonal-tile inverses, doubling inside the block,
 // bordering against the finished rows [0, a)) and the block's share of K^-1 = T^T T (when Kinv is wanted).
 // The block's own inverse is a chain of small launches; on its own stream `xs` (when given) it runs beside
@@ -194,23 +252,40 @@ int enqueue_inverse_block(cugp_gp* g, int a, int b, bool kinv, hipStream_t x, hi
     const size_t off = (size_t)a * TILE * ld + (size_t)a * TILE;
     hipStream_t o = xs ? xs : x;
     launch_trtri_diag(g->dA, ld, a, wb, g->d64, g->dT, g->dU, o, B(g));
-    for (int s = 1; s < wb; s *= 2) {
-        launch_trtri_level(g->dA, g->dT, g->dU, ld, wb, s, 1, o, B(g), off);
-        launch_trtri_level(g->dA, g->dT, g->dU, ld, wb, s, 2, o, B(g), off);
-    }
+    const bool timed = g->prof >= 2;
+    for (int s = 1; s < wb; s *= 2)
+        for (int step = 1; step <= 2; step++) {
+            TimedLaunch tl(g, o, timed && (a + s + step + (int)g->eval_seq) % 8 == 0);   // small launches: one in eight
+            const int wm = launch_trtri_level(g->dA, g->dT, g->dU, ld, wb, s, step, o, B(g), off);
+            if (wm) tl.done(wm == 4 ? KIND_LEVEL4 : KIND_LEVEL2, level_flop(wb, s, step));
+        }
     if (xs) {
         HIPCHK(hipEventRecord(own_done, xs));
         HIPCHK(hipStreamWaitEvent(x, own_done, 0));
     }
     // rows [a, b): their Wt was accumulated chunk by chunk while the earlier blocks became final
-    if (a > 0) launch_trtri_border2(g->dA, g->dT, g->dU, ld, a, wb, x, B(g));
+    const bool timed2 = timed && ((a / (wb > 0 ? wb : 1)) + (int)g->eval_seq) % 2 == 0;   // large launches: every other block
+    if (a > 0) {
+        TimedLaunch tl(g, x, timed2);
+        const int wm = launch_trtri_border2(g->dA, g->dT, g->dU, ld, a, wb, x, B(g));
+        if (wm) tl.done(wm == 4 ? KIND_BORDER4 : KIND_BORDER2, border2_flop(a, wb));
+    }
+    auto kinv_share = [&](hipStream_t st) {
+        TimedLaunch tl(g, st, timed2);
+        const int wm = launch_lauum(g->dU, g->dKinv, ld, a, wb, st, B(g));
+        tl.done(wm == 4 ? KIND_LAUUM4 : KIND_LAUUM2, lauum_flop(a, wb));
+    };
     if (kinv && lq) {
         HIPCHK(hipEventRecord(rows_final, x));
         HIPCHK(hipStreamWaitEvent(lq, rows_final, 0));
-        launch_lauum(g->dU, g->dKinv, ld, a, wb, lq, B(g));
+        kinv_share(lq);
     }
     // ... and these rows, now final, go into the Wt of every row below them
-    if (b < g->nt) launch_trtri_border1(g->dA, g->dT, g->dU, ld, b, g->nt - b, a, b, x, B(g));
+    if (b < g->nt) {
+        TimedLaunch tl(g, x, timed2);
+        const int wm = launch_trtri_border1(g->dA, g->dT, g->dU, ld, b, g->nt - b, a, b, x, B(g));
+        if (wm) tl.done(wm == 4 ? KIND_BORDER4 : KIND_BORDER2, border1_flop(g->nt - b, a, b));
+    }
     if (b == g->nt && g->vec_early) {
         // L^-1 is complete: z = L^-1 y and alpha = L^-T z run here, beside / in front of the last share of K^-1,
         // instead of after it on the main stream (~130 us at N = 8192)
@@ -218,7 +293,7 @@ int enqueue_inverse_block(cugp_gp* g, int a, int b, bool kinv, hipStream_t x, hi
         launch_trmv_upper(g->dU, g->npad, g->npad, g->dz, g->dalpha, x, B(g));
         g->vec_done = true;
     }
-    if (kinv && !lq) launch_lauum(g->dU, g->dKinv, ld, a, wb, x, B(g));
+    if (kinv && !lq) kinv_share(x);
     return CUGP_OK;
 }
 
@@ -317,23 +392,6 @@ int panel_width(const cugp_gp* g)
     return P > 32 ? 32 : P;
 }
 
-// one timed launch (profiling level 2): event pair + bookkeeping
-struct TimedLaunch {
-    cugp_gp* g; hipStream_t s; bool on;
-    TimedLaunch(cugp_gp* g_, hipStream_t s_, bool want) : g(g_), s(s_), on(want && g_->kev_used + 2 <= (int)g_->kev.size())
-    {
-        if (on && hipEventRecord(g->kev[g->kev_used], s) != hipSuccess) on = false;
-    }
-    void done(int kind, double flop)
-    {
-        if (!on) return;
-        if (hipEventRecord(g->kev[g->kev_used + 1], s) != hipSuccess) return;
-        g->kev_kind[g->kev_used / 2] = kind;
-        g->kev_flopv[g->kev_used / 2] = flop;
-        g->kev_used += 2;
-    }
-};
-
 // algorithmic flop of a trailing update over the tile columns [ca, cb) of an nt-tile matrix with kw k tiles:
 // entries on or below the diagonal only (a diagonal tile counts half), multiply + add
 double trailing_flop(int nt, int ca, int cb, int kw)
@@ -389,7 +447,7 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false)
             // one pass, before the next panel's first step widens the near window into them
             TimedLaunch tl(g, m, g->prof >= 2);
             launch_syrk_wide(g->dA, ld, nt, sp.wide_k0, sp.wide_kw, sp.wa0, sp.wa1, (kb / P) & 1, m, B(g));
-            tl.done(1, trailing_flop(nt, sp.wa0, sp.wa1, sp.wide_kw));
+            tl.done(KIND_WIDE, trailing_flop(nt, sp.wa0, sp.wa1, sp.wide_kw));
         }
         // level 2 times a rotating eighth of the step launches (every step is sampled once in 8 evaluations):
         // an event pair around every launch costs several percent of the evaluation
@@ -398,7 +456,7 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false)
         //  freshly non-temporally stored tiles took it 50 us instead of 16)
         launch_syrk_step(g->dA, ld, kb, nt, g->d16, g->d64, g->dlogdet, g->dtickets, m, B(g), sp.wcol,
                          P > 1 ? g_tune[TUNE_STEP_STREAM] : 1);
-        tl.done(0, trailing_flop(nt, kb + 1, kb + 1 + sp.wcol, 1));
+        tl.done(KIND_STEP, trailing_flop(nt, kb + 1, kb + 1 + sp.wcol, 1));
     }
     if (mark && (rc = phase_mark(g, 2))) return rc;         // end of the factorisation on the main stream
     if (w > 0) {
@@ -1094,7 +1152,7 @@ int cugp_get_phase_ms(cugp_gp* g, double ms[6])
 
 int cugp_get_kernel_stats_kind(cugp_gp* g, int kind, double* sum_ms, long long* launches, double* flop, int reset)
 {
-    if (!g || kind < 0 || kind > 1) return CUGP_ERR_INVALID;
+    if (!g || kind < 0 || kind >= KIND_COUNT) return CUGP_ERR_INVALID;
     int rc;
     if ((rc = fetch_eval(g))) return rc;
     if (sum_ms) *sum_ms = g->kst_ms[kind];

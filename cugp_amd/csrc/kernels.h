@@ -76,16 +76,17 @@ int launch_syrk_wide(double* A, int ld, int nt, int k0, int kw, int ca, int cb, 
 
 // ---- triangular inverse by recursive doubling (N7) and K^-1 = U U^T (N8) ----
 // off: element offset of the diagonal sub-matrix (nt tiles) the level works on inside L, T, U
-void launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, int s, int step, hipStream_t st,
-                        Batch bt = {}, size_t off = 0);
+// (these four return the edge of the output tiles they launched with, in 32s: 4 = 128x128, 2 = 64x64, 0 = nothing)
+int launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, int s, int step, hipStream_t st,
+                       Batch bt = {}, size_t off = 0);
 // bordering step 1, one k chunk: Wt(tj < c1, ti in [ra, ra+rw)) (+)= sum_{k in [max(tj,c0), c1)} U[tj][k] L[ti][k]
-void launch_trtri_border1(const double* L, double* T, double* U, int ld, int ra, int rw, int c0, int c1,
-                          hipStream_t st, Batch bt = {});
+int launch_trtri_border1(const double* L, double* T, double* U, int ld, int ra, int rw, int c0, int c1,
+                         hipStream_t st, Batch bt = {});
 // bordering step 2: rows [a, a+w) of the inverse from their finished Wt and the block's own inverse
-void launch_trtri_border2(const double* L, double* T, double* U, int ld, int a, int w, hipStream_t st,
-                          Batch bt = {});
+int launch_trtri_border2(const double* L, double* T, double* U, int ld, int a, int w, hipStream_t st,
+                         Batch bt = {});
 // Kinv(lower tiles < a+w) (+)= contribution of inverse rows [a, a+w); a = 0, w = nt: the whole product
-void launch_lauum(const double* U, double* Kinv, int ld, int a, int w, hipStream_t s, Batch bt = {});
+int launch_lauum(const double* U, double* Kinv, int ld, int a, int w, hipStream_t s, Batch bt = {});
 
 // ---- prediction products ----
 // W[t][i] = sum_{k<=i} Ks[t][k] T[i][k]   (nt_pad x npad, row-major)

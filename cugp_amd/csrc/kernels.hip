@@ -1935,8 +1935,8 @@ int launch_syrk_wide(double* A, int ld, int nt, int k0, int kw, int ca, int cb, 
     return ntiles;
 }
 
-void launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, int s, int step, hipStream_t st,
-                        Batch bt, size_t off)
+int launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, int s, int step, hipStream_t st,
+                       Batch bt, size_t off)
 {
     // pairs p = 0.. : A = [2ps, 2ps+s), B = [2ps+s, min(2ps+2s, nt)); count tiles |A| x |B|
     int tiles = 0;
@@ -1945,63 +1945,69 @@ void launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, i
         if (sb > s) sb = s;
         tiles += s * sb;
     }
-    if (tiles <= 0) return;
+    if (tiles <= 0) return 0;
     // few 128-tiles cannot fill 512 workgroup slots: use 64x64 output tiles (4x the parallelism) there
     set_big_lds();
-    if (tiles * bt.count <= g_tune[TUNE_TRTRI_WM2_MAX])   // (a batched launch fills the chip with fewer tiles each)
+    if (tiles * bt.count <= g_tune[TUNE_TRTRI_WM2_MAX]) {  // (a batched launch fills the chip with fewer tiles each)
         hipLaunchKernelGGL(k_trtri_level<2>, dim3(tiles * 4, bt.count), dim3(256), Geo<2>::LDS, st, L, T, U, ld, nt, s,
                            step, off, bt.tab);
-    else
-        hipLaunchKernelGGL(k_trtri_level<4>, dim3(tiles, bt.count), dim3(256), GEMM_LDS, st, L, T, U, ld, nt, s, step,
-                           off, bt.tab);
+        return 2;
+    }
+    hipLaunchKernelGGL(k_trtri_level<4>, dim3(tiles, bt.count), dim3(256), GEMM_LDS, st, L, T, U, ld, nt, s, step,
+                       off, bt.tab);
+    return 4;
 }
 
 // step 1 of the bordering, spread over time: add the k tiles [c0, c1) (a block of inverse rows that just
 // became final) to Wt(tj < c1, ti in [ra, ra+rw)) for ALL rows below the block
-void launch_trtri_border1(const double* L, double* T, double* U, int ld, int ra, int rw, int c0, int c1,
-                          hipStream_t st, Batch bt)
+int launch_trtri_border1(const double* L, double* T, double* U, int ld, int ra, int rw, int c0, int c1,
+                         hipStream_t st, Batch bt)
 {
     const int tiles = c1 * rw;
-    if (tiles <= 0) return;
+    if (tiles <= 0) return 0;
     set_big_lds();
     if (tiles * bt.count <= g_tune[TUNE_BORDER_WM2_MAX]) {
         hipLaunchKernelGGL(k_trtri_border<2>, dim3(tiles * 4, bt.count), dim3(256), Geo<2>::LDS, st, L, T, U, ld, ra, rw,
                            1, c0, c1, 0, bt.tab);
-    } else {
-        const int nfull = split_round(tiles, bt.count);
-        hipLaunchKernelGGL(k_trtri_border<4>, dim3(nfull + 4 * (tiles - nfull), bt.count), dim3(256), GEMM_LDS, st, L, T,
-                           U, ld, ra, rw, 1, c0, c1, nfull, bt.tab);
+        return 2;
     }
+    const int nfull = split_round(tiles, bt.count);
+    hipLaunchKernelGGL(k_trtri_border<4>, dim3(nfull + 4 * (tiles - nfull), bt.count), dim3(256), GEMM_LDS, st, L, T,
+                       U, ld, ra, rw, 1, c0, c1, nfull, bt.tab);
+    return 4;
 }
 
 // step 2: rows [a, a+w) of the inverse from their finished Wt and the block's own inverse
-void launch_trtri_border2(const double* L, double* T, double* U, int ld, int a, int w, hipStream_t st, Batch bt)
+int launch_trtri_border2(const double* L, double* T, double* U, int ld, int a, int w, hipStream_t st, Batch bt)
 {
     const int tiles = a * w;
-    if (tiles <= 0) return;
+    if (tiles <= 0) return 0;
     set_big_lds();
     if (tiles * bt.count <= g_tune[TUNE_TRTRI_WM2_MAX]) {
         hipLaunchKernelGGL(k_trtri_border<2>, dim3(tiles * 4, bt.count), dim3(256), Geo<2>::LDS, st, L, T, U, ld, a, w, 2,
                            0, 0, 0, bt.tab);
-    } else {
-        const int nfull = split_round(tiles, bt.count);
-        hipLaunchKernelGGL(k_trtri_border<4>, dim3(nfull + 4 * (tiles - nfull), bt.count), dim3(256), GEMM_LDS, st, L, T,
-                           U, ld, a, w, 2, 0, 0, nfull, bt.tab);
+        return 2;
     }
+    const int nfull = split_round(tiles, bt.count);
+    hipLaunchKernelGGL(k_trtri_border<4>, dim3(nfull + 4 * (tiles - nfull), bt.count), dim3(256), GEMM_LDS, st, L, T,
+                       U, ld, a, w, 2, 0, 0, nfull, bt.tab);
+    return 4;
 }
 
-void launch_lauum(const double* U, double* Kinv, int ld, int a, int w, hipStream_t s, Batch bt)
+int launch_lauum(const double* U, double* Kinv, int ld, int a, int w, hipStream_t s, Batch bt)
 {
     set_big_lds();
     const int tiles = tri_count(a + w);
     if (tiles * bt.count <= g_tune[TUNE_LAUUM_WM2_MAX]) {
         hipLaunchKernelGGL(k_lauum<2>, dim3(tiles * 4, bt.count), dim3(256), Geo<2>::LDS, s, U, Kinv, ld, a, w, 0, bt.tab);
+        return 2;
     } else {
         // (a whole-matrix product, a = 0, has k ranges from 1 to a+w tiles, longest first: its tail is short tiles
         //  already; the split is for the block-wise calls, whose tiles all take w k tiles)
         const int nfull = a > 0 ? split_round(tiles, bt.count) : tiles;
         hipLaunchKernelGGL(k_lauum<4>, dim3(nfull + 4 * (tiles - nfull), bt.count), dim3(256), GEMM_LDS, s, U, Kinv, ld,
                            a, w, nfull, bt.tab);
+        return 4;
     }
 }
 

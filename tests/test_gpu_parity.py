@@ -837,4 +837,14 @@ def test_bench_multi_rank_code_path_on_one_rank():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and np.isfinite(line["ll_last"])
-    assert line["roofline"]["launches"] >= 0
+    assert line["roofline"]["launches_timed"] > 0 and line["roofline"]["kernel"].startswith("k_")
+    # the metric workload carries BASELINE configs 5 and 4 as sub-runs through the same process group (here one rank:
+    # 16 and 4 experts on this GPU), so that an N-GPU run of the driver yields the strong-scaling curve
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--rehearse-rccl", "--steps", "2", "--warmup", "1",
+                        "--cpu-sample", "0", "--sub-steps", "2"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    for name, K in (("bcm_si24000_16shard", 16), ("bcm_si6000_4chunk", 4)):
+        sub = line[name]
+        assert sub["experts"] == K and sub["experts_per_gpu"] == K and sub["ms_per_eval"] > 0 and np.isfinite(sub["ll_last"])
+    assert line["roofline"]["kernel"].split(" ")[0] in line["roofline_kernels"]

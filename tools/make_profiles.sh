@@ -1,7 +1,7 @@
 #!/bin/bash
-# Regenerate everything under profiles/ for one round on the GPU box:  tools/make_profiles.sh r02
+# Regenerate everything under profiles/ for one round on the GPU box:  tools/make_profiles.sh r03
 # Outputs land in gpurun_out/profiles_<tag>/ (copy the ones to keep into profiles/).
-tag=${1:-r02}
+tag=${1:-r03}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/profiles_$tag
 mkdir -p $O
@@ -38,5 +38,5 @@ for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY 
   rm -rf $R/gpurun_out/pmc_$t
   rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$t -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 > $R/gpurun_out/pmc_$t.log 2>&1 || echo "pass $t failed"
 done
-cd $R && python3 tools/pmc_summary.py && cp profiles/${tag}_pmc_summary.json $O/
+cd $R && python3 tools/pmc_summary.py $R/gpurun_out $tag && cp profiles/${tag}_pmc_summary.json $O/
 ls -la $O

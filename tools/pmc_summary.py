@@ -1,6 +1,10 @@
-"""Summarise rocprofv3 PMC passes (tools/pmc.sh) into profiles/r02_pmc_summary.json.
+"""Summarise rocprofv3 PMC passes (tools/pmc.sh, tools/make_profiles.sh) into profiles/<tag>_pmc_summary.json
+(python tools/pmc_summary.py [gpurun_out dir] [tag]).
 FETCH_SIZE is doubled before use: on gfx950 it reports half the bytes of wide coalesced reads
-(MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact for 16-byte-per-lane stores.  Units: KiB."""
+(MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact for 16-byte-per-lane stores.  Units: KiB.
+mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / (kernel time x shader clock x SIMDs of the chip): the counter is in
+cycles summed over the SIMDs (MI355X_MICROARCH.md, row 's_memtime tick vs SQ PMC units'), the kernel time is the
+dispatch's own begin..end in the same pass (counter passes serialise the dispatches: isolated durations)."""
 import collections
 import csv
 import glob
@@ -10,12 +14,14 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out")
-KERNELS = ("k_syrk_step", "k_syrk_wide", "k_lauum", "k_trtri_level", "k_trtri_border", "k_trtri_diag", "k_build", "k_trace", "k_potf2",
-           "k_trsm_inv64")
+tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
+CLOCK_HZ, SIMDS = 2.4e9, 256 * 4
+KERNELS = ("k_syrk_step", "k_syrk_wide", "k_lauum<4>", "k_lauum<2>", "k_trtri_level<4>", "k_trtri_level<2>",
+           "k_trtri_border<4>", "k_trtri_border<2>", "k_trtri_diag", "k_build", "k_trace", "k_potf2", "k_trsm_inv64")
 
 
-def load(tag):
-    f = glob.glob(os.path.join(src, "pmc_%s" % tag, "*", "*counter_collection.csv"))
+def load(t):
+    f = glob.glob(os.path.join(src, "pmc_%s" % t, "*", "*counter_collection.csv"))
     f.sort(key=os.path.getmtime)                       # gpurun_out keeps earlier runs: take the newest
     return list(csv.DictReader(open(f[-1]))) if f else []
 
@@ -28,11 +34,11 @@ def short(name):
 
 
 out = {"note": __doc__.strip(), "kernels": {}}
-for tag, key in (("FETCH_SIZE", "fetch_kib_raw"), ("WRITE_SIZE", "write_kib")):
+for t, key in (("FETCH_SIZE", "fetch_kib_raw"), ("WRITE_SIZE", "write_kib")):
     agg, n = collections.defaultdict(float), collections.Counter()
-    for r in load(tag):
+    for r in load(t):
         k = short(r["Kernel_Name"])
-        if k and r["Counter_Name"] == tag:
+        if k and r["Counter_Name"] == t:
             agg[k] += float(r["Counter_Value"])
             n[k] += 1
     for k in agg:
@@ -40,21 +46,28 @@ for tag, key in (("FETCH_SIZE", "fetch_kib_raw"), ("WRITE_SIZE", "write_kib")):
         d[key] = agg[k]
         d["launches"] = n[k]
 sq = collections.defaultdict(lambda: collections.defaultdict(float))
+dur = collections.defaultdict(float)
+seen = set()
 for r in load("SQ_WAVE_CYCLES"):
     k = short(r["Kernel_Name"])
     if k:
         sq[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Dispatch_Id"] not in seen:               # one row per counter: count a dispatch's duration once
+            seen.add(r["Dispatch_Id"])
+            dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
 for k, v in sq.items():
     d = out["kernels"].setdefault(k, {})
     wc = v.get("SQ_WAVE_CYCLES", 0.0)
     d["sq"] = {n: x for n, x in v.items()}
+    d["kernel_time_s_in_counter_pass"] = dur[k]
+    if dur[k] > 0:
+        d["mfma_busy_frac"] = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (dur[k] * CLOCK_HZ * SIMDS)
     if wc:
-        d["mfma_busy_per_wave_cycle"] = v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / wc
         d["wait_inst_any_frac"] = v.get("SQ_WAIT_INST_ANY", 0.0) / wc
         d["lds_bank_conflict_frac"] = v.get("SQ_LDS_BANK_CONFLICT", 0.0) / wc
 for k, d in out["kernels"].items():
     if "fetch_kib_raw" in d and "write_kib" in d and d.get("launches"):
         d["hbm_bytes_per_launch"] = (2.0 * d["fetch_kib_raw"] + d["write_kib"]) * 1024.0 / d["launches"]
-json.dump(out, open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", "%s_pmc_summary.json" % tag), "w"), indent=1)
 for k, d in out["kernels"].items():
     print(k, {a: (round(b, 4) if isinstance(b, float) else b) for a, b in d.items() if a != "sq"})
