@@ -19,7 +19,8 @@ VALUE_FN = C.CFUNCTYPE(None, C.c_void_p, _dp, _dp)
 GRADIENT_FN = C.CFUNCTYPE(None, C.c_void_p, _dp, _dp)
 
 CUGP_OK = 0
-ERR_NAMES = {-1: "CUGP_ERR_INVALID", -2: "CUGP_ERR_NOMEM", -3: "CUGP_ERR_DEVICE", -4: "CUGP_ERR_NODEVICE"}
+ERR_NAMES = {-1: "CUGP_ERR_INVALID", -2: "CUGP_ERR_NOMEM", -3: "CUGP_ERR_DEVICE", -4: "CUGP_ERR_NODEVICE",
+             -5: "CUGP_ERR_BUSY"}
 
 
 class CugpError(RuntimeError):

@@ -15,6 +15,8 @@
 #include <vector>
 
 #include "../../include/cugp.h"
+#include <hip/hip_runtime.h>
+
 #include "group.h"
 
 // the experts of one device: evaluated as one group of shared launches when their shapes allow it
@@ -159,20 +161,39 @@ int cugp_bcm_get_loghyper(const cugp_bcm* b, double hp[3])
     return CUGP_OK;
 }
 
+// after an error half-way through an evaluation: fetch whatever is still in flight (results ignored) so that no group
+// or expert keeps its "pending" flag -- the next evaluation then starts from a clean state instead of finding the
+// shared-launch path "already in flight" for ever
+static void bcm_drain(cugp_bcm* b)
+{
+    std::vector<double> lk, gk3;
+    for (DeviceSet& ds : b->sets) {
+        if (ds.grouped_now && ds.group) {
+            lk.assign(ds.idx.size(), 0.0);
+            gk3.assign(3 * ds.idx.size(), 0.0);
+            (void)cugp_group_fetch(ds.group, lk.data(), gk3.data());
+        } else {
+            double l, g3[3];
+            for (int k : ds.idx) (void)cugp_loglik_grad_fetch(b->experts[k], &l, g3);
+        }
+        ds.grouped_now = false;
+    }
+}
+
 // all experts of all devices in flight (a group of shared launches per device where possible, else one stream
 // per expert) before anything is read back
 static int bcm_enqueue_all(cugp_bcm* b)
 {
+    for (DeviceSet& ds : b->sets) ds.grouped_now = false;
     for (DeviceSet& ds : b->sets) {
-        ds.grouped_now = false;
         if (ds.group) {
             const int rc = cugp_group_enqueue(ds.group, 1);
             if (rc == CUGP_OK) { ds.grouped_now = true; continue; }
-            if (rc != CUGP_ERR_INVALID) return rc;       // INVALID: not possible as a group right now
+            if (rc != CUGP_ERR_INVALID) { bcm_drain(b); return rc; }   // INVALID: not possible as a group right now
         }
         for (int k : ds.idx) {
             const int rc = cugp_loglik_grad_enqueue(b->experts[k], 1);
-            if (rc) return rc;
+            if (rc) { bcm_drain(b); return rc; }
         }
     }
     return CUGP_OK;
@@ -191,10 +212,11 @@ int cugp_bcm_loglik_grad_rows(cugp_bcm* b, double* rows)
         lk.assign(n, 0.0);
         gk3.assign(3 * n, 0.0);
         if (ds.grouped_now) {
-            if ((rc = cugp_group_fetch(ds.group, lk.data(), gk3.data()))) return rc;
+            if ((rc = cugp_group_fetch(ds.group, lk.data(), gk3.data()))) { ds.grouped_now = false; bcm_drain(b); return rc; }
+            ds.grouped_now = false;
         } else {
             for (size_t i = 0; i < n; i++)
-                if ((rc = cugp_loglik_grad_fetch(b->experts[ds.idx[i]], &lk[i], &gk3[3 * i]))) return rc;
+                if ((rc = cugp_loglik_grad_fetch(b->experts[ds.idx[i]], &lk[i], &gk3[3 * i]))) { bcm_drain(b); return rc; }
         }
         for (size_t i = 0; i < n; i++) {
             const size_t k = (size_t)ds.idx[i];
@@ -213,6 +235,15 @@ int cugp_bcm_loglik_grad_rows_device(cugp_bcm* b, double* dev_rows, const int* s
 {
     if (!b || !dev_rows || !slot) return CUGP_ERR_INVALID;
     if (b->sets.size() != 1) return CUGP_ERR_INVALID;
+    {   // dev_rows must be device memory of the handle's device (a host pointer or another GPU's buffer would fault
+        // inside the copy kernels, or silently land elsewhere)
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, dev_rows) != hipSuccess || at.type != hipMemoryTypeDevice ||
+            at.device != b->sets[0].device) {
+            (void)hipGetLastError();
+            return CUGP_ERR_INVALID;
+        }
+    }
     int rc = bcm_enqueue_all(b);
     if (rc) return rc;
     DeviceSet& ds = b->sets[0];

@@ -1412,7 +1412,7 @@ int cugp_group_enqueue(cugp_group* gr, int want_grad)
     cugp_gp* lead = gr->experts[0];
     const int k = (int)gr->experts.size(), nt = lead->nt;
     int rc;
-    if (gr->pending) return fail(CUGP_ERR_INVALID, "cugp_group_enqueue: an evaluation is already in flight");
+    if (gr->pending) return fail(CUGP_ERR_BUSY, "cugp_group_enqueue: an evaluation is already in flight");
     if (nt > g_tune[TUNE_GROUP_MAX_TILES]) return CUGP_ERR_INVALID;
     // the batched step kernel puts its workgroups on gridDim.y (65535 at most): larger experts go one by one
     if ((long long)nt * (nt + 1) / 2 + 16 > 65535) return CUGP_ERR_INVALID;

@@ -33,6 +33,7 @@ extern "C" {
 #define CUGP_ERR_NOMEM (-2)     /* host or device allocation failed */
 #define CUGP_ERR_DEVICE (-3)    /* HIP runtime error; see cugp_last_error() */
 #define CUGP_ERR_NODEVICE (-4)  /* no gfx950 device visible */
+#define CUGP_ERR_BUSY (-5)      /* an evaluation of this handle / group is still in flight: fetch it first */
 
 typedef struct cugp_gp cugp_gp;    /* one expert: Covsum / the cuda_gp.cu global state */
 typedef struct cugp_bcm cugp_bcm;  /* a set of experts resident on one GPU: class BCM */

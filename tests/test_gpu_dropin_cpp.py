@@ -69,3 +69,39 @@ def test_cpp_dropin_driver(tmp_path, si128, golden_si128, oracle):
     assert np.allclose(r["bcm_pred_var"], bv, rtol=1e-8, atol=1e-8)
     bf, _ = b.cg_solve()
     assert np.allclose(r["bcm_cg_final_hp"], bf, atol=5e-5)
+
+
+def test_cpp_rccl_driver_one_rank(tmp_path):
+    """tests/cpp/rccl_driver.cpp: the multi-process BCM driver a C++ host writes on libcugp + RCCL (one rank per GPU,
+    ncclCommInitRank, device-resident K x 4 rows -> ncclAllReduce -> sum in expert order; PoE partial sums ->
+    ncclAllReduce -> cugp_poe_finish), run at ONE rank on the one GPU of this box: bit-identical to the library's
+    single-process sums and to the Python BCM on the same experts."""
+    import cugp_amd.gp as gp
+    from conftest import synth
+    K, rows, d, nt = 3, 700, 10, 9
+    X, y = synth(K * rows, seed=31)
+    Xt = np.ascontiguousarray(X[:nt] * 0.9 + 0.05)
+    hp = np.array([np.log(3.0), 0.0, np.log(0.1)])
+    data = tmp_path / "data.bin"
+    with open(data, "wb") as f:
+        for a in (X, y, Xt, hp):
+            np.ascontiguousarray(a, dtype=np.float64).tofile(f)
+    exe = str(tmp_path / "rccl_driver")
+    libdir = os.path.join(ROOT, "cugp_amd", "lib")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-w", os.path.join(ROOT, "tests", "cpp", "rccl_driver.cpp"),
+                           "-I" + os.path.join(ROOT, "include"), "-L" + libdir, "-lcugp", "-lrccl",
+                           "-Wl,-rpath," + libdir, "-o", exe])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([exe, str(tmp_path / "nccl.id"), "0", "1", str(data), str(K), str(rows), str(d), str(nt), "0"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, (out.stdout[-1000:], out.stderr[-2000:])
+    r = json.loads(out.stdout[out.stdout.index("{"):])
+    assert r["ll"] == r["direct_ll"] and r["grad"] == r["direct_grad"]                      # bit for bit
+    assert r["pred_mean"] == r["direct_pred_mean"] and r["pred_var"] == r["direct_pred_var"]
+    b = gp.BCM.split(X, y, K)
+    b.set_BCM_log_hyperparam(hp)
+    ll, g, per = b.loglik_grad()
+    m, v = b.compute_BCM_test_means_and_var(Xt)
+    b.close()
+    assert r["ll"] == ll and np.array_equal(r["grad"], g) and np.array_equal(r["per_expert_ll"], per)
+    assert np.array_equal(r["pred_mean"], m) and np.array_equal(r["pred_var"], v)

@@ -848,3 +848,60 @@ def test_bench_multi_rank_code_path_on_one_rank():
         sub = line[name]
         assert sub["experts"] == K and sub["experts_per_gpu"] == K and sub["ms_per_eval"] > 0 and np.isfinite(sub["ll_last"])
     assert line["roofline"]["kernel"].split(" ")[0] in line["roofline_kernels"]
+
+
+def _two_rank_device_rows_worker(rank, world, port, q):
+    import os as _os
+    _os.environ["MASTER_ADDR"] = "127.0.0.1"
+    _os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cugp_amd.bcm import ShardedBCM
+    K, rows = 5, 300
+    X, y = synth(K * rows, seed=55)
+    experts = [(X[k * rows:(k + 1) * rows], y[k * rows:(k + 1) * rows]) if k % world == rank else None for k in range(K)]
+    b = ShardedBCM(experts, rank=rank, world=world, device=0, comm_device=torch.device("cuda", 0))
+    assert b._on_device and b.mine == [k for k in range(K) if k % world == rank]
+    b.set_loghyper([np.log(3.0), 0.0, np.log(0.1)])
+    ll, g, per = b.loglik_grad()
+    send = b._send.cpu().numpy()
+    q.put((rank, ll, g, per, send))
+    dist.barrier()
+    b.close()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_device_rows_slots_and_zeros(gp_mod):
+    """The device-resident row path of ShardedBCM (cugp_bcm_loglik_grad_rows_device -> all-reduce of the K x 4 device
+    tensor) with TWO ranks, both on GPU 0 of this box (gloo moves the device tensors): every rank's rows land in its
+    own slots, every other slot is an exact zero, and the all-reduced sums equal the single-process BCM bit for bit."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_two_rank_device_rows_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    K, rows = 5, 300
+    X, y = synth(K * rows, seed=55)
+    b = gp_mod.BCM.split(X, y, K)
+    b.set_BCM_log_hyperparam([np.log(3.0), 0.0, np.log(0.1)])
+    ll, g, per = b.loglik_grad()
+    ref_rows = b.loglik_grad_rows()
+    b.close()
+    for rank, rll, rg, rper, send in res:
+        assert rll == ll and np.array_equal(rg, g) and np.array_equal(rper, per)
+        for k in range(K):
+            if k % 2 == rank:
+                assert np.array_equal(send[k], ref_rows[k]), (rank, k)
+            else:
+                assert np.all(send[k] == 0.0), (rank, k, send[k])
