@@ -11,7 +11,7 @@ python3 $R/bench.py > $O/${tag}_bench_line.json 2> $O/bench.err || exit 1
 for ov in 1 0; do
   name=$([ $ov = 1 ] && echo bench || echo bench_overlap0)
   rm -rf /tmp/prof_$name
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python3 $R/bench.py --overlap $ov --cpu-sample 0 > $O/${tag}_${name}_line_under_rocprof.json 2> $O/$name.err || exit 1
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python3 $R/bench.py --overlap $ov --cpu-sample 0 --sub-steps 0 > $O/${tag}_${name}_line_under_rocprof.json 2> $O/$name.err || exit 1
   cp $(find /tmp/prof_$name -name '*kernel_stats.csv' | head -1) $O/${tag}_${name}_n8192_kernel_stats.csv
 done
 python3 $R/bench.py --rows 1500 --experts-total 16 --cpu-sample 0 > $O/${tag}_bench_bcm16_line.json 2>> $O/bench.err
@@ -36,7 +36,7 @@ done
 for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_LDS_BANK_CONFLICT" "FETCH_SIZE" "WRITE_SIZE"; do
   t=$(echo $pass | cut -d' ' -f1)
   rm -rf $R/gpurun_out/pmc_$t
-  rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$t -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 > $R/gpurun_out/pmc_$t.log 2>&1 || echo "pass $t failed"
+  rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$t -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 --sub-steps 0 > $R/gpurun_out/pmc_$t.log 2>&1 || echo "pass $t failed"
 done
 cd $R && python3 tools/pmc_summary.py $R/gpurun_out $tag && cp profiles/${tag}_pmc_summary.json $O/
 ls -la $O
