@@ -497,101 +497,133 @@ __global__ __launch_bounds__(256) void k_mfma_peak(double* sink, int iters)
 // ------------------------------------------------------------------------------------------
 // panel solve with the two 64x64 diagonal inverses (T00, T11) of the factor block: per 16-row strip
 //   X0 = A0 T00^T ;  Z1 = A1 - X0 L10^T ;  X1 = Z1 T11^T
-// one workgroup (4 waves) per strip, wave w owns the 16-column tile w of each half; everything is kept
-// transposed so results in C/D layout are the next product's B operand (k = (lane>>4) + 4*reg); the
-// tiles the other waves need pass through 8 KiB of LDS.  <= 48 dependent MFMAs per wave.
-// Every operand of the three phases is requested before the first MFMA (68 doubles per lane): the strip used to
-// pay a global-memory latency per phase and per k tile (the loads sat inside loops with a wave-dependent trip
-// count); entries of the inverses above the diagonal micro tiles are loaded but never multiplied.
+// One workgroup of EIGHT waves per strip.  Everything is kept transposed, so a result in C/D layout is the next
+// product's B operand (k = (lane>>4) + 4*reg) and passes from wave to wave through LDS as it stands.
+// Round 3: the three 64x64 matrices and the strip come into LDS with coalesced 16-byte loads (L10 and T11 wait in
+// registers until the buffer is free) and the MFMA operands are read from there.  The strip used to load every
+// operand from global memory in MFMA layout -- 16 rows x 32 bytes per instruction, 68 such loads per lane, 96 KB of
+// inverses per strip: ~280 MB of L2 sector traffic for a 63-tile panel, which took the launch 17-20 us (round-3
+// timeline) on the factorisation's serial path; and each of the three dependent MFMA chains (<= 16 long) ran on one
+// wave per SIMD at 138 cycles per MFMA.  Now wave (w, h) takes the k sub-ranges r in {2h, 2h+1} of column tile w:
+// chains of <= 8, the two waves of a SIMD (w, w+4) interleaving at the pipe's full rate; the two halves meet in LDS.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void strip_solve(double* __restrict__ A, const double* __restrict__ d64, int ld, int kb,
-                                            int strip, double (*xbuf)[4][64])
-{
-    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int c = lane & 15, g = lane >> 4;
-    const int k0 = kb * TILE;
-    double* Arow = A + (size_t)(k0 + TILE + strip * MT + c) * ld + k0;   // my row of the strip (as B operand / output)
-    const double* T00 = d64 + (size_t)kb * 8192 + (w * MT + c) * 64 + g;
-    const double* T11 = T00 + 4096;
-    const double* L10 = A + (size_t)(k0 + 64 + w * MT + c) * ld + k0 + g;
-    const d4 zero4 = (d4){0.0, 0.0, 0.0, 0.0};
-    double t00[4][4], t11[4][4], a0[4][4], l10[4][4];
-    d4 z;
-#pragma unroll
-    for (int kt = 0; kt < 4; kt++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            t00[kt][r] = T00[kt * MT + 4 * r];
-            a0[kt][r] = Arow[kt * MT + g + 4 * r];
-        }
-#pragma unroll
-    for (int r = 0; r < 4; r++) z[r] = Arow[64 + w * MT + g + 4 * r];
-#pragma unroll
-    for (int kt = 0; kt < 4; kt++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            l10[kt][r] = -L10[kt * MT + 4 * r];
-            t11[kt][r] = T11[kt * MT + 4 * r];
-        }
-    // phase 1: X0^T[w] = sum_{kt <= w} T00[w][kt] A0^T[kt]
-    // (each phase runs two independent accumulation chains: a dependent fp64 MFMA chain issues at half rate)
-    d4 x0 = zero4, x0b = zero4;
-#pragma unroll
-    for (int kt = 0; kt < 4; kt++)
-        if (kt <= w) {
-#pragma unroll
-            for (int r = 0; r < 4; r += 2) {
-                x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(t00[kt][r], a0[kt][r], x0, 0, 0, 0);
-                x0b = __builtin_amdgcn_mfma_f64_16x16x4f64(t00[kt][r + 1], a0[kt][r + 1], x0b, 0, 0, 0);
-            }
-        }
-    x0 += x0b;
-#pragma unroll
-    for (int r = 0; r < 4; r++) xbuf[w][r][lane] = x0[r];
-    __syncthreads();
-    // phase 2: Z1^T[w] = A1^T[w] - sum_kt L10[w][kt] X0^T[kt]
-    d4 zb = zero4;
-#pragma unroll
-    for (int kt = 0; kt < 4; kt++) {
-#pragma unroll
-        for (int r = 0; r < 4; r += 2) {
-            z = __builtin_amdgcn_mfma_f64_16x16x4f64(l10[kt][r], xbuf[kt][r][lane], z, 0, 0, 0);
-            zb = __builtin_amdgcn_mfma_f64_16x16x4f64(l10[kt][r + 1], xbuf[kt][r + 1][lane], zb, 0, 0, 0);
-        }
-    }
-    z += zb;
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        xbuf[w][r][lane] = z[r];
-        Arow[w * MT + g + 4 * r] = x0[r];
-    }
-    __syncthreads();
-    // phase 3: X1^T[w] = sum_{kt <= w} T11[w][kt] Z1^T[kt]
-    d4 x1 = zero4, x1b = zero4;
-#pragma unroll
-    for (int kt = 0; kt < 4; kt++)
-        if (kt <= w) {
-#pragma unroll
-            for (int r = 0; r < 4; r += 2) {
-                x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(t11[kt][r], xbuf[kt][r][lane], x1, 0, 0, 0);
-                x1b = __builtin_amdgcn_mfma_f64_16x16x4f64(t11[kt][r + 1], xbuf[kt][r + 1][lane], x1b, 0, 0, 0);
-            }
-        }
-    x1 += x1b;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-        Arow[64 + w * MT + g + 4 * r] = x1[r];
-    }
-}
+constexpr int TRSM_TS = 68;                          // row stride (doubles) of the 64x64 matrix in LDS: rows 4 doubles apart mod 32
+constexpr int TRSM_SS = 132;                         // ... of the 16 x 128 strip
+constexpr int TRSM_LDS = (64 * TRSM_TS + MT * TRSM_SS + 3 * 4 * 4 * 64) * 8;   // + half sums, X0^T, Z1^T: 76288 B
 
-__global__ __launch_bounds__(256) void k_trsm_inv64(double* __restrict__ A, const double* __restrict__ d64,
+__global__ __launch_bounds__(512) void k_trsm_inv64(double* __restrict__ A, const double* __restrict__ d64,
                                                     int ld, int kb, const ExpertPtrs* __restrict__ bt)
 {
     if (bt) { A = GP(bt[blockIdx.y].A); d64 = GP(bt[blockIdx.y].d64); }
-    __shared__ double xbuf[4][4][64];
-    __builtin_amdgcn_s_setprio(3);
-    strip_solve(A, d64, ld, kb, blockIdx.x, xbuf);
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* Tm = sm;                                    // T00, then -L10, then T11
+    double* Sb = Tm + 64 * TRSM_TS;                     // the strip: A in, X out (row-major)
+    double* Sc = Sb + MT * TRSM_SS;                     // half sums of the waves h = 1: [w][r][lane]
+    double* X0 = Sc + 4 * 4 * 64;                       // X0^T tiles as B operands: [kt][r][lane]
+    double* Z1 = X0 + 4 * 4 * 64;
+    __builtin_amdgcn_s_setprio(3);                      // on the factorisation's serial chain (see k_syrk_step)
+    const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int w = wv & 3, h = wv >> 2, c = lane & 15, g = lane >> 4;
+    const int k0 = kb * TILE;
+    double* Ag = A + (size_t)(k0 + TILE + blockIdx.x * MT) * ld + k0;
+    const double* T00 = d64 + (size_t)kb * 8192;
+    const double* T11 = T00 + 4096;
+    const double* L10 = A + (size_t)(k0 + 64) * ld + k0;
+    // coalesced requests for everything the strip will read: 4 chunks of 16 B per thread and 64x64 matrix, 2 of the strip
+    d2 rt[4], rl[4], r1[4], ra[2];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int q = t + 512 * i, row = q >> 5, cp = (q & 31) * 2;
+        rt[i] = *(const d2*)(T00 + row * 64 + cp);
+        rl[i] = *(const d2*)(L10 + (size_t)row * ld + cp);
+        r1[i] = *(const d2*)(T11 + row * 64 + cp);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int q = t + 512 * i, row = q >> 6, cp = (q & 63) * 2;
+        ra[i] = *(const d2*)(Ag + (size_t)row * ld + cp);
+    }
+    auto fill_tm = [&](const d2 (&r)[4], double sign) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int q = t + 512 * i, row = q >> 5, cp = (q & 31) * 2;
+            *(d2*)(Tm + row * TRSM_TS + cp) = sign * r[i];
+        }
+    };
+    fill_tm(rt, 1.0);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int q = t + 512 * i, row = q >> 6, cp = (q & 63) * 2;
+        *(d2*)(Sb + row * TRSM_SS + cp) = ra[i];
+    }
+    __syncthreads();
+    const d4 zero4 = (d4){0.0, 0.0, 0.0, 0.0};
+    const double* tm = Tm + (w * MT + c) * TRSM_TS + g + 8 * h;        // my row of the matrix, my k sub-range
+    // acc += sum over the k tiles kt < nkt of M[w][kt] (from Tm) times the B tiles bop[kt][r][lane], r in {2h, 2h+1}
+    auto chain = [&](d4 acc, const double* bop, int nkt) {
+#pragma unroll
+        for (int kt = 0; kt < 4; kt++)
+            if (kt < nkt) {
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tm[kt * MT], bop[(kt * 4 + 2 * h) * 64 + lane], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tm[kt * MT + 4], bop[(kt * 4 + 2 * h + 1) * 64 + lane], acc, 0, 0, 0);
+            }
+        return acc;
+    };
+    // phase 1: X0^T[w] = sum_{kt <= w} T00[w][kt] A0^T[kt]   (B operand straight from the strip: A0[row c][k])
+    d4 x = zero4;
+#pragma unroll
+    for (int kt = 0; kt < 4; kt++)
+        if (kt <= w) {
+            x = __builtin_amdgcn_mfma_f64_16x16x4f64(tm[kt * MT], Sb[c * TRSM_SS + kt * MT + g + 8 * h], x, 0, 0, 0);
+            x = __builtin_amdgcn_mfma_f64_16x16x4f64(tm[kt * MT + 4], Sb[c * TRSM_SS + kt * MT + g + 8 * h + 4], x, 0, 0, 0);
+        }
+    if (h == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) Sc[(w * 4 + r) * 64 + lane] = x[r];
+    }
+    __syncthreads();                                    // T00 and A0 have been read; the half sums are in LDS
+    d4 z = zero4;
+    if (h == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const double v = x[r] + Sc[(w * 4 + r) * 64 + lane];
+            X0[(w * 4 + r) * 64 + lane] = v;
+            Sb[c * TRSM_SS + w * MT + g + 4 * r] = v;                   // X0 is final: into the strip, over A0
+            z[r] = Sb[c * TRSM_SS + 64 + w * MT + g + 4 * r];           // A1^T[w]
+        }
+    }
+    fill_tm(rl, -1.0);
+    __syncthreads();
+    // phase 2: Z1^T[w] = A1^T[w] - sum_kt L10[w][kt] X0^T[kt]
+    z = chain(z, X0, 4);
+    if (h == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) Sc[(w * 4 + r) * 64 + lane] = z[r];
+    }
+    __syncthreads();
+    if (h == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) Z1[(w * 4 + r) * 64 + lane] = z[r] + Sc[(w * 4 + r) * 64 + lane];
+    }
+    fill_tm(r1, 1.0);
+    __syncthreads();
+    // phase 3: X1^T[w] = sum_{kt <= w} T11[w][kt] Z1^T[kt]
+    d4 x1 = chain(zero4, Z1, w + 1);
+    if (h == 1) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) Sc[(w * 4 + r) * 64 + lane] = x1[r];
+    }
+    __syncthreads();
+    if (h == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) Sb[c * TRSM_SS + 64 + w * MT + g + 4 * r] = x1[r] + Sc[(w * 4 + r) * 64 + lane];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; i++) {                       // the solved strip back to global memory, whole rows
+        const int q = t + 512 * i, row = q >> 6, cp = (q & 63) * 2;
+        *(d2*)(Ag + (size_t)row * ld + cp) = *(const d2*)(Sb + row * TRSM_SS + cp);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1859,6 +1891,7 @@ static void set_big_lds()
                            (const void*)k_predict_gemm, (const void*)k_test_gemm};
     for (const void* f : gemm4) attr(f, GEMM_LDS);
     attr((const void*)k_trtri_diag, TRTRI_LDS);
+    attr((const void*)k_trsm_inv64, TRSM_LDS);
     if (e != hipSuccess) { g_attr_err = e; return; }
     g_attr_done |= 1ull << dev;
 }
@@ -1875,7 +1908,8 @@ void launch_trsm_inv64(double* A, const double* d64, int ld, int kb, int nt, hip
 {
     const int nstrips = (nt - kb - 1) * (TILE / MT);
     if (nstrips <= 0) return;
-    hipLaunchKernelGGL(k_trsm_inv64, dim3(nstrips, bt.count), dim3(256), 0, s, A, d64, ld, kb, bt.tab);
+    set_big_lds();
+    hipLaunchKernelGGL(k_trsm_inv64, dim3(nstrips, bt.count), dim3(512), TRSM_LDS, s, A, d64, ld, kb, bt.tab);
 }
 
 void launch_trtri_diag(const double* A, int ld, int kb, int nblocks, const double* d64, double* T, double* U,
