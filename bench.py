@@ -46,14 +46,14 @@ HBM_PEAK_GBS = 8000.0                                # MI355X HBM3E (MI355X_MICR
 PMC_SUMMARY = "profiles/r03_pmc_summary.json"        # rocprofv3 --pmc passes of this command (tools/pmc.sh)
 # kernels timed by the library at profiling level 2 (cugp_get_kernel_stats_kind): name as rocprofv3 prints it, what it
 # is, and one launch in how many is timed
-KINDS = {0: ("k_syrk_step", "Cholesky near-window trailing update + next diagonal block, K=128 per launch", 8),
+KINDS = {0: ("k_syrk_step", "Cholesky near-window trailing update + next diagonal block, K=128 per launch", 16),
          1: ("k_syrk_wide", "Cholesky far trailing update, K=128*panel per launch", 1),
-         2: ("k_trtri_border<4>", "bordering steps of L^-1, 128x128 output tiles", 2),
-         3: ("k_trtri_border<2>", "bordering steps of L^-1, 64x64 output tiles", 2),
-         4: ("k_lauum<4>", "shares of K^-1 = L^-T L^-1, 128x128 output tiles", 2),
-         5: ("k_lauum<2>", "shares of K^-1, 64x64 output tiles", 2),
-         6: ("k_trtri_level<4>", "doubling inside a block of inverse rows, 128x128 output tiles", 8),
-         7: ("k_trtri_level<2>", "doubling inside a block of inverse rows, 64x64 output tiles", 8)}
+         2: ("k_trtri_border<4>", "bordering steps of L^-1, 128x128 output tiles", 4),
+         3: ("k_trtri_border<2>", "bordering steps of L^-1, 64x64 output tiles", 4),
+         4: ("k_lauum<4>", "shares of K^-1 = L^-T L^-1, 128x128 output tiles", 4),
+         5: ("k_lauum<2>", "shares of K^-1, 64x64 output tiles", 4),
+         6: ("k_trtri_level<4>", "doubling inside a block of inverse rows, 128x128 output tiles", 16),
+         7: ("k_trtri_level<2>", "doubling inside a block of inverse rows, 64x64 output tiles", 16)}
 
 
 def synth(n, d, seed):
@@ -210,7 +210,7 @@ def main():
         first.set_overlap(False)
         for kd in KINDS:
             first.kernel_stats(reset=True, kind=kd)
-        for i in range(8):                        # level-2 profiling times every 8th step launch, rotating
+        for i in range(16):                       # level-2 profiling times every 16th step launch, rotating
             first.set_loghyperparam(HP0 + 1e-3 * ((i % 7) - 3))
             first.loglik_grad()
         iso = {kd: first.kernel_stats(kind=kd) for kd in KINDS}
@@ -334,15 +334,15 @@ def main():
             ks, kw = kst[0], kst[1]
             if ks["launches"] > 0 and kw["launches"] > 0:
                 # the two kernels of the factorisation's trailing update together: their flop over the sum of their
-                # durations (every wide launch is timed, one step launch in 8: scale the step sample up)
-                fl = kw["flop"] + 8.0 * ks["flop"]
-                ms = kw["sum_ms"] + 8.0 * ks["sum_ms"]
+                # durations (every wide launch is timed, one step launch in 16: scale the step sample up)
+                fl = kw["flop"] + 16.0 * ks["flop"]
+                ms = kw["sum_ms"] + 16.0 * ks["sum_ms"]
                 tu = {"what": "k_syrk_wide + k_syrk_step together (N^3/3 flop of the factorisation)",
                       "achieved": fl / (ms * 1e-3) / 1e12, "unit": "TFLOP/s", "peak": MFMA_F64_PEAK_TFLOPS,
                       "wide_share_of_flop": kw["flop"] / fl}
                 tu["frac"] = tu["achieved"] / MFMA_F64_PEAK_TFLOPS
                 if iso and iso[0]["launches"] > 0 and iso[1]["launches"] > 0:
-                    ia = (iso[1]["flop"] + 8.0 * iso[0]["flop"]) / ((iso[1]["sum_ms"] + 8.0 * iso[0]["sum_ms"]) * 1e-3) / 1e12
+                    ia = (iso[1]["flop"] + 16.0 * iso[0]["flop"]) / ((iso[1]["sum_ms"] + 16.0 * iso[0]["sum_ms"]) * 1e-3) / 1e12
                     tu["isolated_achieved"], tu["isolated_frac"] = ia, ia / MFMA_F64_PEAK_TFLOPS
                 out["roofline_trailing_update"] = tu
         if timed_launches and ph["kbuild"] == ph["kbuild"]:

@@ -48,7 +48,7 @@ int fail(int code, const char* what, hipError_t e = hipSuccess)
 constexpr int NPHASE = 6;
 constexpr int MAX_KEV = 4096;   // per-launch event pairs kept between resets
 constexpr int GRAPH_MAX_TILES = 24;   // evaluations up to 3072 rows are replayed as captured graphs
-constexpr int PROF_STRIDE = 8;  // profiling level 2 times every 8th trailing-update launch, rotating
+constexpr int PROF_STRIDE = 16; // profiling level 2 times every 16th step launch, rotating (an event pair costs ~5 us of device time)
 // kinds of timed launches (cugp_get_kernel_stats_kind): the kernels as rocprofv3 names them
 enum { KIND_STEP = 0, KIND_WIDE = 1, KIND_BORDER4 = 2, KIND_BORDER2 = 3, KIND_LAUUM4 = 4, KIND_LAUUM2 = 5,
        KIND_LEVEL4 = 6, KIND_LEVEL2 = 7, KIND_COUNT = 8 };
@@ -255,7 +255,7 @@ int enqueue_inverse_block(cugp_gp* g, int a, int b, bool kinv, hipStream_t x, hi
     const bool timed = g->prof >= 2;
     for (int s = 1; s < wb; s *= 2)
         for (int step = 1; step <= 2; step++) {
-            TimedLaunch tl(g, o, timed && (a + s + step + (int)g->eval_seq) % 8 == 0);   // small launches: one in eight
+            TimedLaunch tl(g, o, timed && (a + s + step + (int)g->eval_seq) % 16 == 0);  // small launches: one in sixteen
             const int wm = launch_trtri_level(g->dA, g->dT, g->dU, ld, wb, s, step, o, B(g), off);
             if (wm) tl.done(wm == 4 ? KIND_LEVEL4 : KIND_LEVEL2, level_flop(wb, s, step));
         }
@@ -264,7 +264,7 @@ int enqueue_inverse_block(cugp_gp* g, int a, int b, bool kinv, hipStream_t x, hi
         HIPCHK(hipStreamWaitEvent(x, own_done, 0));
     }
     // rows [a, b): their Wt was accumulated chunk by chunk while the earlier blocks became final
-    const bool timed2 = timed && ((a / (wb > 0 ? wb : 1)) + (int)g->eval_seq) % 2 == 0;   // large launches: every other block
+    const bool timed2 = timed && ((a / (wb > 0 ? wb : 1)) + (int)g->eval_seq) % 4 == 0;   // large launches: every fourth block
     if (a > 0) {
         TimedLaunch tl(g, x, timed2);
         const int wm = launch_trtri_border2(g->dA, g->dT, g->dU, ld, a, wb, x, B(g));

@@ -119,10 +119,10 @@ int cugp_set_profiling(cugp_gp *gp, int level /* 0 off, 1 phases, 2 phases + per
 int cugp_get_phase_ms(cugp_gp *gp, double ms[6]);
 int cugp_get_kernel_stats(cugp_gp *gp, double *sum_ms, long long *launches, double *flop, int reset);
 /* the same per kernel, as rocprofv3 names them: kind 0 = k_syrk_step (near-window update + next diagonal block,
- * K = 128; timed one launch in 8, rotating), 1 = k_syrk_wide (the far trailing matrix once per panel, K = 128 * panel
+ * K = 128; timed one launch in 16, rotating), 1 = k_syrk_wide (the far trailing matrix once per panel, K = 128 * panel
  * width), 2 / 3 = k_trtri_border<4> / <2> (bordering steps of L^-1) and 4 / 5 = k_lauum<4> / <2> (shares of K^-1):
- * timed for every other block of inverse rows, 6 / 7 = k_trtri_level<4> / <2> (doubling inside a block of rows; timed
- * one launch in 8).  flop = algorithmic
+ * timed for every fourth block of inverse rows, 6 / 7 = k_trtri_level<4> / <2> (doubling inside a block of rows; timed
+ * one launch in 16).  flop = algorithmic
  * (entries on or below the diagonal, a triangular k tile counted half), multiply + add */
 int cugp_get_kernel_stats_kind(cugp_gp *gp, int kind, double *sum_ms, long long *launches, double *flop, int reset);
 void *cugp_get_stream(cugp_gp *gp);          /* hipStream_t of the handle */
