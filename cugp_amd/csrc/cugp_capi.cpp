@@ -174,13 +174,13 @@ Batch B(const cugp_gp* g) { return g->grp ? g->grp->bt : Batch{}; }
 unsigned g_cfg_epoch = 1;          // bumped by cugp_set_tuning: captured graphs carry launch shapes
 
 // block rows per hand-over to the other streams: about a sixteenth of the matrix, at least 2 tiles (interleaved
-// A/B at 16, 32, 64 and 79 tiles: 2, 2-3, 4, 5 were the best), or as tuned; 0 = no hand-over (everything on the
-// main stream after the factorisation)
+// A/B at 16, 32, 64 and 79 tiles: 2, 2-3, 4, 5 were the best), single tiles up to 8 tiles (600 and 1000 rows: -9 %
+// and -3 % against 2), or as tuned; 0 = no hand-over (everything on the main stream after the factorisation)
 int pipe_block(const cugp_gp* g, bool with_inverse)
 {
     const bool overlap = g->grp ? g->grp->overlap : g->overlap;
     int w = (with_inverse && overlap) ? g_tune[TUNE_PIPE_BLOCK] : 0;
-    if (w < 0) w = (g->nt + 8) / 16 > 2 ? (g->nt + 8) / 16 : 2;
+    if (w < 0) w = g->nt <= 8 ? 1 : ((g->nt + 8) / 16 > 2 ? (g->nt + 8) / 16 : 2);
     return w >= g->nt ? 0 : w;
 }
 
@@ -420,14 +420,9 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false)
     const int near = g_tune[TUNE_NEAR_TILES];
     hipStream_t m = g->stream;                              // the whole factorisation is ordered on the handle's stream
     int nblk = 0, done = 0;                                 // blocks forked so far, block rows handed over
-    // Small matrices: every hand-over costs the main stream a ~11-us bubble (event record + cross-stream wait) and the
-    // chip is mostly idle anyway, so the first nt - 2w block rows go over in ONE block, late, and only the last two
-    // blocks keep the short tail of the fine-grained schedule (-1.5 % at 1000 and 1500 rows; from 2000 rows on the
-    // inverse needs its early start: +8...19 %, hence nt <= 12).
-    // Groups of experts share the launches: with many experts the inverse is throughput work again and wants its early
-    // start (16 x 1500: +4 % when late; 2 x 1500, 5 x 1000: -2...-3 %): at most 64 tile rows over the whole group.
-    const int group_rows = nt * (g->grp ? g->grp->bt.count : 1);
-    const int first = (w > 0 && nt <= g_tune[TUNE_LATE_FORK_NT] && group_rows <= 64 && nt - 2 * w > w) ? nt - 2 * w : w;
+    // (Round 2 handed the first nt - 2w block rows of small matrices over in ONE late block: every hand-over cost the
+    //  main stream a bubble the ~50-us chain steps could not afford.  With the round-3 chain -- ~32 us per step -- the
+    //  fine-grained hand-over wins at every size again: 1500 rows 0.77 -> 0.65 ms, 2 x 1500 rows 0.80 -> 0.73 ms.)
     g->eval_seq++;
     if (g->grp) HIPCHK(hipMemsetAsync(g->grp->tickets, 0, (size_t)g->grp->bt.count * nt * sizeof(unsigned), m));
     else HIPCHK(hipMemsetAsync(g->dtickets, 0, (size_t)nt * sizeof(unsigned), m));
@@ -436,7 +431,7 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false)
         launch_trsm_inv64(g->dA, g->d64, ld, kb, nt, m, B(g));
         // block rows < kb+1 of L are final, and so are the columns <= kb of every row below them
         const int b = kb + 1;
-        if (w > 0 && b - done >= (nblk == 0 ? first : w)) {
+        if (w > 0 && b - done >= w) {
             if ((rc = fork_inverse_block(g, done, b, nblk, m))) return rc;
             done = b;
             nblk++;

@@ -12,7 +12,7 @@ constexpr int TILE = 128;          // tile edge of every fp64 MFMA product and o
 enum { TUNE_LAUUM_WM2_MAX = 0,   // K^-1 product: use 64x64 tiles when there are at most this many 128-tiles
        TUNE_TRTRI_WM2_MAX = 1,   // inverse level: same rule
        TUNE_SYRK_REM_MAX = 2,    // trailing update: split the last partial round into 64x64 quarters when it has at most this many tiles
-       TUNE_PIPE_BLOCK = 3,      // inverse rows (tiles) handed to the other streams at a time while the factorisation runs; 0 = after it, < 0 = about nt/16
+       TUNE_PIPE_BLOCK = 3,      // inverse rows (tiles) handed to the other streams at a time while the factorisation runs; 0 = after it, < 0 = about nt/16 (1 up to 8 tiles)
        TUNE_BORDER_WM2_MAX = 4,  // bordering step 1 (uniform K): 64x64 tiles when there are at most this many 128-tiles
        TUNE_GRAPHS = 5,          // replay single-stream evaluations as a captured HIP graph (1) or launch by launch (0)
        TUNE_GROUP_OVERLAP = 6,   // grouped experts: inverse blocks on the other streams beside the factorisation (1) or after it (0)
@@ -22,10 +22,9 @@ enum { TUNE_LAUUM_WM2_MAX = 0,   // K^-1 product: use 64x64 tiles when there are
        TUNE_PANEL_MIN_NT = 10,   // ... only from this many tiles on (small matrices are bound by the chain alone)
        TUNE_LAUUM_STREAM = 11,   // the K^-1 share of an inverse block on its own stream beside the next block's bordering: 0 never, 1 expert groups only, 2 always
        TUNE_STEP_STREAM = 12,    // two-speed step kernel: non-temporal accesses to the C tiles (1) or plain ones (0)
-       TUNE_LATE_FORK_NT = 13,   // matrices of at most this many tiles hand their first nt - 2w block rows to the inverse streams in ONE block
-       TUNE_SPLIT_REM_MAX = 14,  // uniform-K launches (block-wise K^-1 share, bordering, wide update): a last round of at most this many tiles runs as 64x64 quarters
-       TUNE_STEP_QUARTER_MAX = 15, // step kernel: launches of at most this many 64x64 workgroups run ALL their tiles as quarters (chain-bound tail)
-       TUNE_COUNT = 16 };
+       TUNE_SPLIT_REM_MAX = 13,  // uniform-K launches (block-wise K^-1 share, bordering, wide update): a last round of at most this many tiles runs as 64x64 quarters
+       TUNE_STEP_QUARTER_MAX = 14, // step kernel: launches of at most this many 64x64 workgroups run ALL their tiles as quarters (chain-bound tail)
+       TUNE_COUNT = 15 };
 extern int g_tune[TUNE_COUNT];
 
 struct HyperScalars;

@@ -1845,7 +1845,7 @@ __global__ __launch_bounds__(256) void k_predict_finish(const double* __restrict
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-int g_tune[TUNE_COUNT] = {768, 1200, 384, -1, 511, 1, 1, 1 << 20, 16, 500, 32, 1, 1, 12, 256, 1536};   // defaults chosen by interleaved A/B runs (tools/ab.py)
+int g_tune[TUNE_COUNT] = {768, 1200, 384, -1, 511, 1, 1, 1 << 20, 16, 500, 32, 1, 1, 256, 1536};   // defaults chosen by interleaved A/B runs (tools/ab.py)
 
 static inline int tri_count(int n) { return n * (n + 1) / 2; }
 
