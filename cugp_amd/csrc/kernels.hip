@@ -17,7 +17,9 @@
 // flight while stage t is multiplied.  LDS image: [k-pair plane, padded by 16 B][row][2 doubles]
 // -- fragment reads are 256 contiguous bytes per 32 lanes (conflict-free ds_read_b64) at one
 // per-lane base + immediate offsets (no address arithmetic in the loop: VALU issue costs MFMA
-// issue on gfx950), staging writes (8 lanes = 8 planes of one row) land on 8 different 16-B slots.
+// issue on gfx950), staging writes (8 lanes = 8 planes of one row) land on 8 different 16-B slots
+// (two rows of a 16-lane group overlap in 7 of them: 2-way, the ~5 % SQ_LDS_BANK_CONFLICT of the tile kernels;
+// a 32-byte pad removes the overlap and changes no timing: the K loop does not wait for these writes).
 //
 // Matrices are npad x npad row-major with npad = ceil(n/128)*128; the padding of K is the
 // identity, so every kernel works on whole tiles and the factor, inverse, log-determinant and

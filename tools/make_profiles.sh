@@ -39,4 +39,7 @@ for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY 
   rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$t -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 --sub-steps 0 > $R/gpurun_out/pmc_$t.log 2>&1 || echo "pass $t failed"
 done
 cd $R && python3 tools/pmc_summary.py $R/gpurun_out $tag && cp profiles/${tag}_pmc_summary.json $O/
+# the factorisation's chain kernels alone, with in-kernel cycle stamps (built in the build container: see the sources' headers)
+[ -x $R/tools/bin/chain_bench ] && $R/tools/bin/chain_bench > $O/${tag}_chain_bench.txt 2>&1
+[ -x $R/tools/bin/panel_bench ] && $R/tools/bin/panel_bench >> $O/${tag}_chain_bench.txt 2>&1
 ls -la $O
