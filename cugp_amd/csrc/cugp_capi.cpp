@@ -287,11 +287,24 @@ int enqueue_inverse_block(cugp_gp* g, int a, int b, bool kinv, hipStream_t x, hi
         if (wm) tl.done(wm == 4 ? KIND_BORDER4 : KIND_BORDER2, border1_flop(g->nt - b, a, b));
     }
     if (b == g->nt && g->vec_early) {
-        // L^-1 is complete: z = L^-1 y and alpha = L^-T z run here, beside / in front of the last share of K^-1,
-        // instead of after it on the main stream (~130 us at N = 8192)
-        launch_trmv_lower(g->dT, g->npad, g->npad, g->dy, g->dz, x, B(g));
-        launch_trmv_upper(g->dU, g->npad, g->npad, g->dz, g->dalpha, x, B(g));
+        // L^-1 is complete: z = L^-1 y and alpha = L^-T z run BESIDE the last share of K^-1 (~130 us at N = 8192)
+        // instead of after it on the main stream: on the stream of the block's own inverse (idle by now) when the
+        // share follows on this one
+        hipStream_t vs = x;
+        if (kinv && !lq && xs && rows_final) {
+            HIPCHK(hipEventRecord(rows_final, x));
+            HIPCHK(hipStreamWaitEvent(xs, rows_final, 0));
+            vs = xs;
+        }
+        launch_trmv_lower(g->dT, g->npad, g->npad, g->dy, g->dz, vs, B(g));
+        launch_trmv_upper(g->dU, g->npad, g->npad, g->dz, g->dalpha, vs, B(g));
         g->vec_done = true;
+        if (vs != x) {
+            HIPCHK(hipEventRecord(own_done, xs));
+            if (kinv && !lq) kinv_share(x);
+            HIPCHK(hipStreamWaitEvent(x, own_done, 0));             // x's last event covers both again
+            return CUGP_OK;
+        }
     }
     if (kinv && !lq) kinv_share(x);
     return CUGP_OK;
@@ -316,8 +329,7 @@ int fork_inverse_block(cugp_gp* g, int a, int b, int idx, hipStream_t from)
     HIPCHK(hipStreamWaitEvent(g->aux, g->bev[idx], 0));
     HIPCHK(hipStreamWaitEvent(g->aux2, g->bev[idx], 0));
     const bool own = kinv_stream(g);
-    return enqueue_inverse_block(g, a, b, true, g->aux, g->aux2, g->oev[idx], own ? g->lq : nullptr,
-                                 own ? g->lev[idx] : nullptr);
+    return enqueue_inverse_block(g, a, b, true, g->aux, g->aux2, g->oev[idx], own ? g->lq : nullptr, g->lev[idx]);
 }
 
 // What step kb of the two-speed factorisation launches (pure column arithmetic, shared with the test hook

@@ -634,6 +634,10 @@ __global__ __launch_bounds__(512) void k_trsm_inv64(double* __restrict__ A, cons
 constexpr int KT = 64;      // kernel-build tile
 constexpr int DC = 16;      // feature chunk staged per pass
 
+// the 4 columns of a thread's 4x4 micro-tile inside the 64-column tile: two adjacent pairs, 32 apart, so that the 16
+// lanes of a row make one 256-byte run per 16-byte access (columns 4 tx + b made two half-used runs of 512 bytes)
+__device__ __forceinline__ int col4(int tx, int b) { return (b >> 1) * 32 + tx * 2 + (b & 1); }
+
 // squared distances of a 4x4 micro-tile, accumulated over d in index order without FMA
 // contraction so that the value matches the reference's sub / mul / add sequence bit for bit
 __device__ __forceinline__ void sqdist_4x4(const double* __restrict__ X, const double* __restrict__ Y, int nx,
@@ -658,7 +662,7 @@ __device__ __forceinline__ void sqdist_4x4(const double* __restrict__ X, const d
         for (int c = 0; c < dc; c++) {
             double xv[4], yv[4];
 #pragma unroll
-            for (int a = 0; a < 4; a++) { xv[a] = xs[ty * 4 + a][c]; yv[a] = ys[tx * 4 + a][c]; }
+            for (int a = 0; a < 4; a++) { xv[a] = xs[ty * 4 + a][c]; yv[a] = ys[col4(tx, a)][c]; }
 #pragma unroll
             for (int a = 0; a < 4; a++)
 #pragma unroll
@@ -668,6 +672,24 @@ __device__ __forceinline__ void sqdist_4x4(const double* __restrict__ X, const d
                 }
         }
     }
+}
+
+// a / b for many a and one b: with y = RN(1/b) from one real division, q0 = RN(a y), the exact remainder a - b q0 by
+// FMA and q = RN(q0 + rem y) give the correctly rounded quotient (Markstein; 2e7 random pairs identical to a / b) in
+// three instructions instead of the ~18 of a full IEEE division per matrix entry.  Only while b and 1/b are far
+// from the ends of the exponent range (the optimisers do walk l^2 = exp(2 theta) to infinity: a / inf must stay 0,
+// 0 * inf is NaN): DivBy::y == 0 selects the real division (uniform over the launch).
+struct DivBy { double b, y; };
+__device__ __forceinline__ DivBy div_prepare(double b)
+{
+    return DivBy{b, (b > 1e-100 && b < 1e100) ? 1.0 / b : 0.0};
+}
+__device__ __forceinline__ double div_by(double a, const DivBy& d)
+{
+    if (d.y == 0.0) return a / d.b;
+    const double q0 = a * d.y;
+    const double rem = __builtin_fma(-q0, d.b, a);
+    return __builtin_fma(rem, d.y, q0);
 }
 
 // hd (when given): hyper-scalars resident in device memory -- a captured graph of the evaluation is replayed
@@ -686,32 +708,32 @@ __global__ __launch_bounds__(256) void k_build(const double* __restrict__ X, int
     double d2v[4][4];
     sqdist_4x4(X, X, n, n, d, i0, j0, xs, ys, d2v);
     double out[4][4];
+    const DivBy dl = div_prepare(h.ell_sq);
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            const int i = i0 + ty * 4 + a, j = j0 + tx * 4 + b;
+            const int i = i0 + ty * 4 + a, j = j0 + col4(tx, b);
+            const bool in = i < n && j < n;
             double v;
-            if (i < n && j < n && full == 2) {
-                v = (i == j) ? 0.0 : d2v[a][b] / h.ell_sq;               // covkernel.cpp:143-151 (squared distance / c)
-            } else if (i < n && j < n) {
-                v = h.signal_var * exp(-d2v[a][b] * 0.5 / h.ell_sq);     // covkernel.cpp:89
-                if (i == j) v += h.noise_var;                            // covkernel.cpp:93-94
+            if (full == 2) {
+                v = (i == j) ? 0.0 : div_by(d2v[a][b], dl);    // covkernel.cpp:143-151 (squared distance / c)
             } else {
-                v = (i == j) ? 1.0 : 0.0;                                // identity padding
+                v = h.signal_var * exp(div_by(-d2v[a][b] * 0.5, dl));   // covkernel.cpp:89
+                if (i == j) v += h.noise_var;                            // covkernel.cpp:93-94
             }
-            out[a][b] = v;
+            out[a][b] = in ? v : ((i == j) ? 1.0 : 0.0);                // identity padding
         }
 #pragma unroll
     for (int a = 0; a < 4; a++) {
-        double* p = K + (size_t)(i0 + ty * 4 + a) * npad + j0 + tx * 4;
+        double* p = K + (size_t)(i0 + ty * 4 + a) * npad + j0 + tx * 2;
         *(d2*)p = (d2){out[a][0], out[a][1]};
-        *(d2*)(p + 2) = (d2){out[a][2], out[a][3]};
+        *(d2*)(p + 32) = (d2){out[a][2], out[a][3]};
     }
     if (full && ti != tj) {
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            double* p = K + (size_t)(j0 + tx * 4 + b) * npad + i0 + ty * 4;
+            double* p = K + (size_t)(j0 + col4(tx, b)) * npad + i0 + ty * 4;
             *(d2*)p = (d2){out[0][b], out[1][b]};
             *(d2*)(p + 2) = (d2){out[2][b], out[3][b]};
         }
@@ -731,18 +753,19 @@ __global__ __launch_bounds__(256) void k_cross(const double* __restrict__ X, int
     double d2v[4][4];
     // the reference subtracts X[i] - xtest (covkernel.cpp:112); squares are sign-independent but keep the order
     sqdist_4x4(Xt, X, nt, n, d, t0, i0, xs, ys, d2v);
+    const DivBy dl = div_prepare(h.ell_sq);
 #pragma unroll
     for (int a = 0; a < 4; a++) {
         const int tr = t0 + ty * 4 + a;
         double o[4];
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            const int i = i0 + tx * 4 + b;
-            o[b] = (tr < nt && i < n) ? h.signal_var * exp(-d2v[a][b] * 0.5 / h.ell_sq) : 0.0;
+            const int i = i0 + col4(tx, b);
+            o[b] = (tr < nt && i < n) ? h.signal_var * exp(div_by(-d2v[a][b] * 0.5, dl)) : 0.0;
         }
-        double* p = Ks + (size_t)tr * npad + i0 + tx * 4;
+        double* p = Ks + (size_t)tr * npad + i0 + tx * 2;
         *(d2*)p = (d2){o[0], o[1]};
-        *(d2*)(p + 2) = (d2){o[2], o[3]};
+        *(d2*)(p + 32) = (d2){o[2], o[3]};
     }
 }
 
@@ -1744,23 +1767,24 @@ __global__ __launch_bounds__(256) void k_trace(const double* __restrict__ X, int
     double d2v[4][4];
     sqdist_4x4(X, X, n, n, d, i0, j0, xs, ys, d2v);
     double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const DivBy dl = div_prepare(h.ell_sq);
     double aj[4];
 #pragma unroll
-    for (int b = 0; b < 4; b++) aj[b] = alpha[j0 + tx * 4 + b];
+    for (int b = 0; b < 4; b++) aj[b] = alpha[j0 + col4(tx, b)];
 #pragma unroll
     for (int a = 0; a < 4; a++) {
         const int i = i0 + ty * 4 + a;
         const double ai = alpha[i];
-        const double* kr = Kinv + (size_t)i * npad + j0 + tx * 4;
-        d2 k01 = *(const d2*)kr, k23 = *(const d2*)(kr + 2);
+        const double* kr = Kinv + (size_t)i * npad + j0 + tx * 2;
+        d2 k01 = *(const d2*)kr, k23 = *(const d2*)(kr + 32);
         const double kv[4] = {k01[0], k01[1], k23[0], k23[1]};
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-            const int j = j0 + tx * 4 + b;
+            const int j = j0 + col4(tx, b);
             if (i < n && j < n && (ti != tj || j <= i)) {
                 const double w = kv[b] - ai * aj[b];
-                double kse = h.signal_var * exp(-d2v[a][b] * 0.5 / h.ell_sq);
-                const double sd = d2v[a][b] / h.ell_sq;
+                double kse = h.signal_var * exp(div_by(-d2v[a][b] * 0.5, dl));
+                const double sd = div_by(d2v[a][b], dl);
                 if (i == j) {
                     kse += h.noise_var;
                     s1 += w * (kse * sd);
@@ -1782,7 +1806,8 @@ __global__ __launch_bounds__(256) void k_trace(const double* __restrict__ X, int
 // single workgroup: deterministic final sums and the scalar formulas
 //   LL = -0.5 (z'z + 2 sum log L_ii + n * 1.83787)                     covkernel.cpp:127
 //   g0 = s1/2, g1 = (2 s2 - 2 sn2 s3)/2, g2 = (2 sn2 s3)/2              covkernel.cpp:244-261
-__global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ z, int npad, int n,
+constexpr int FIN_THREADS = 1024;     // one workgroup; at N = 8192 it sums 3 x 8256 trace partials and 8192 squares (23 us with 256 threads)
+__global__ __launch_bounds__(FIN_THREADS) void k_finalize(const double* __restrict__ z, int npad, int n,
                                                   const double* __restrict__ logdet_part, int nt,
                                                   const double* __restrict__ part, int nblocks,
                                                   HyperScalars h_arg, const HyperScalars* __restrict__ hd,
@@ -1794,18 +1819,18 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ z, 
         if (part) part = GP(e.part);
     }
     const HyperScalars h = hd ? *hd : h_arg;
-    __shared__ double red[5][256];
+    __shared__ double red[5][FIN_THREADS];
     const int t = threadIdx.x;
     double q = 0.0, ld = 0.0, s[3] = {0.0, 0.0, 0.0};
-    for (int i = t; i < npad; i += 256) q += z[i] * z[i];
-    for (int i = t; i < nt; i += 256) ld += logdet_part[i];
+    for (int i = t; i < npad; i += FIN_THREADS) q += z[i] * z[i];
+    for (int i = t; i < nt; i += FIN_THREADS) ld += logdet_part[i];
     if (part)
-        for (int i = t; i < nblocks; i += 256) {
+        for (int i = t; i < nblocks; i += FIN_THREADS) {
             s[0] += part[(size_t)i * 3]; s[1] += part[(size_t)i * 3 + 1]; s[2] += part[(size_t)i * 3 + 2];
         }
     red[0][t] = q; red[1][t] = ld; red[2][t] = s[0]; red[3][t] = s[1]; red[4][t] = s[2];
     __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
+    for (int w = FIN_THREADS / 2; w > 0; w >>= 1) {
         if (t < w)
             for (int c = 0; c < 5; c++) red[c][t] += red[c][t + w];
         __syncthreads();
@@ -2101,7 +2126,7 @@ void launch_trace(const double* X, int n, int d, int npad, HyperScalars h, const
 void launch_finalize(const double* z, int npad, int n, const double* logdet_part, int nt, const double* part,
                      int nblocks, HyperScalars h, double* out, hipStream_t s, const HyperScalars* hd, Batch bt)
 {
-    hipLaunchKernelGGL(k_finalize, dim3(1, bt.count), dim3(256), 0, s, z, npad, n, logdet_part, nt, part, nblocks, h,
+    hipLaunchKernelGGL(k_finalize, dim3(1, bt.count), dim3(FIN_THREADS), 0, s, z, npad, n, logdet_part, nt, part, nblocks, h,
                        hd, out, bt.tab);
 }
 

@@ -71,6 +71,26 @@ def test_K_train_vs_oracle(gp_mod, oracle, si128, hp):
     assert np.max(np.abs(K - Ko) / np.maximum(np.abs(Ko), 1e-300)) <= 4.5e-16
 
 
+@pytest.mark.parametrize("theta0", [100.0, 130.0, 400.0, -100.0, -130.0, -400.0])
+def test_K_train_at_extreme_length_scales(gp_mod, oracle, si128, theta0):
+    """Where RPROP / CG walk when a direction is flat: l^2 = exp(2 theta) up to infinity and down to 0.  The build
+    divides by l^2 through a rounded reciprocal only while both are far from the ends of the exponent range
+    (kernels.hip div_by); beyond, the real division keeps a / inf = 0 and -0 / 0 = NaN as covkernel.cpp:89 has them."""
+    X, y = si128
+    hp = [theta0, 0.3, -1.0]
+    g = gp_mod.Covsum(*X.shape)
+    g.set_data(X, y)
+    g.set_loghyperparam(hp)
+    with np.errstate(all="ignore"):
+        K, Ko = g.compute_K_train(), oracle.K_train(X, hp)
+        assert np.array_equal(np.isnan(K), np.isnan(Ko))
+        fin = ~np.isnan(Ko)
+        assert np.max(np.abs(K[fin] - Ko[fin]) / np.maximum(np.abs(Ko[fin]), 1e-300)) <= 4.5e-16
+        ll, llo = g.compute_loglikelihood(), oracle.loglik(X, y, hp)
+    assert (np.isnan(ll) and np.isnan(llo)) or abs(ll - llo) <= 1e-8 * abs(llo)
+    g.close()
+
+
 def test_K_train_ragged_d(gp_mod, oracle):
     """n not a multiple of the tile, d not a multiple of the feature chunk (17 > 16)."""
     X, y = synth(203, d=17, seed=3, scale=2.0)
