@@ -108,8 +108,8 @@ void launch_trace(const double* X, int n, int d, int npad, HyperScalars h, const
                   Batch bt = {});
 // out[0..3] = LL, g0, g1, g2  (LL only when part == nullptr)
 void launch_finalize(const double* z, int npad, int n, const double* logdet_part, int nt, const double* part,
-                     int nblocks, HyperScalars h, double* out, hipStream_t s, const HyperScalars* hd = nullptr,
-                     Batch bt = {});
+                     int nblocks, HyperScalars h, double* out, double* hout, hipStream_t s,
+                     const HyperScalars* hd = nullptr, Batch bt = {});   // hout: pinned host copy of the results ([expert][8]) or null
 // per-device function attributes (dynamic LDS sizes) for the current device; the launchers do it lazily, a
 // stream capture must not.  Returns the hipError_t of a failed hipFuncSetAttribute (0 = fine).
 int prepare_kernels();
