@@ -342,8 +342,8 @@ int enqueue_last_block(cugp_gp* g, int a, int idx)
         if (wm) tl.done(wm == 4 ? KIND_BORDER4 : KIND_BORDER2, border2_flop(a, wb));
     }
     // z = L^-1 y, alpha = L^-T z: beside the share on aux2 when they are long enough to be worth two hand-overs
-    // (~130 us at 8192 rows against ~10 us per hand-over; 14 us at 1500 rows: in line there)
-    const bool beside = g->vec_early && nt > 16;
+    // (~130 us at 8192 rows, ~90 us for 16 x 1500 rows against ~10 us per hand-over; 14 us at 1500 rows: in line there)
+    const bool beside = g->vec_early && nt * (g->grp ? g->grp->bt.count : 1) > 24;
     if (g->vec_early) {
         hipStream_t vs = m;
         if (beside) {
