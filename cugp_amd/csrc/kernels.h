@@ -52,7 +52,8 @@ struct HyperScalars {              // exp(2*theta) evaluated on the host, as the
 // lower 64x64 tiles of K (+ mirror when `full`), padding rows/cols >= n set to identity
 // hd (optional, also below): read the hyper-scalars from device memory instead of the argument
 void launch_kbuild(const double* X, int n, int d, int npad, HyperScalars h, double* K, bool full,
-                   hipStream_t s, const HyperScalars* hd = nullptr, Batch bt = {});
+                   hipStream_t s, const HyperScalars* hd = nullptr, Batch bt = {}, unsigned* tickets = nullptr);
+                   // tickets: the factorisation's arrival counters (npad/128 per expert), zeroed by the launch when given
 // S[i][j] = |x_i - x_j|^2 / c, zero diagonal, full symmetric (N2, covkernel.cpp:130-157)
 void launch_sqdist(const double* X, int n, int d, int npad, double c, double* S, hipStream_t s);
 // Ks[t][i] = sf2 * exp(-0.5*|x_i - xt_t|^2 / l^2), row-major nt_pad x npad (pad = 0)   (N12)

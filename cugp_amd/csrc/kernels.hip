@@ -696,9 +696,17 @@ __device__ __forceinline__ double div_by(double a, const DivBy& d)
 // with new hyper-parameters by refreshing that one buffer instead of every kernel's arguments
 __global__ __launch_bounds__(256) void k_build(const double* __restrict__ X, int n, int d, int npad,
                                                HyperScalars h_arg, const HyperScalars* __restrict__ hd,
-                                               double* __restrict__ K, int full, const ExpertPtrs* __restrict__ bt)
+                                               double* __restrict__ K, int full, unsigned* __restrict__ tickets,
+                                               const ExpertPtrs* __restrict__ bt)
 {
-    if (bt) { X = GP(bt[blockIdx.y].X); n = bt[blockIdx.y].n; K = GP(bt[blockIdx.y].A); }
+    if (bt) {
+        X = GP(bt[blockIdx.y].X); n = bt[blockIdx.y].n; K = GP(bt[blockIdx.y].A);
+        if (tickets) tickets = GP(bt[blockIdx.y].tickets);
+    }
+    // tickets (when given): the factorisation's per-step arrival counters, zeroed here instead of by a memset node in
+    // front of the factorisation (one launch boundary less on a chain that small matrices are bound by)
+    if (tickets && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < npad / TILE; i += 256) tickets[i] = 0u;
     const HyperScalars h = hd ? *hd : h_arg;
     __shared__ double xs[KT][DC + 1], ys[KT][DC + 1];
     int ti, tj;
@@ -1883,17 +1891,17 @@ int g_tune[TUNE_COUNT] = {768, 1200, 384, -1, 511, 1, 1, 1 << 20, 16, 500, 32, 1
 static inline int tri_count(int n) { return n * (n + 1) / 2; }
 
 void launch_kbuild(const double* X, int n, int d, int npad, HyperScalars h, double* K, bool full, hipStream_t s,
-                   const HyperScalars* hd, Batch bt)
+                   const HyperScalars* hd, Batch bt, unsigned* tickets)
 {
     hipLaunchKernelGGL(k_build, dim3(tri_count(npad / KT), bt.count), dim3(256), 0, s, X, n, d, npad, h, hd, K,
-                       full ? 1 : 0, bt.tab);
+                       full ? 1 : 0, tickets, bt.tab);
 }
 
 void launch_sqdist(const double* X, int n, int d, int npad, double c, double* S, hipStream_t s)
 {
     HyperScalars h{c, 0.0, 0.0};
     hipLaunchKernelGGL(k_build, dim3(tri_count(npad / KT)), dim3(256), 0, s, X, n, d, npad, h,
-                       (const HyperScalars*)nullptr, S, 2, (const ExpertPtrs*)nullptr);
+                       (const HyperScalars*)nullptr, S, 2, (unsigned*)nullptr, (const ExpertPtrs*)nullptr);
 }
 
 void launch_kcross(const double* X, int n, int d, int npad, const double* Xt, int nt, int ntpad, HyperScalars h,
