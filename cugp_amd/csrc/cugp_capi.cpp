@@ -492,6 +492,7 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false, bool tickets
     int nblk = 0, done = 0;                                 // blocks forked so far, block rows handed over
     struct Fork { int a, b; };
     std::vector<Fork> forks;
+    const bool chain_first = nt * (g->grp ? g->grp->bt.count : 1) <= 24;
     // (Round 2 handed the first nt - 2w block rows of small matrices over in ONE late block: every hand-over cost the
     //  main stream a bubble the ~50-us chain steps could not afford.  With the round-3 chain -- ~32 us per step -- the
     //  fine-grained hand-over wins at every size again: 1500 rows 0.77 -> 0.65 ms, 2 x 1500 rows 0.80 -> 0.73 ms.)
@@ -523,17 +524,21 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false, bool tickets
                          P > 1 ? g_tune[TUNE_STEP_STREAM] : 1);
         tl.done(KIND_STEP, trailing_flop(nt, kb + 1, kb + 1 + sp.wcol, 1));
         if (hand_over) {
-            forks.push_back({done, b});
+            // The block's own 6-8 launches take the host 15-35 us.  Where a chain step is shorter than that (small
+            // matrices: ~35 us per step) they are enqueued behind the WHOLE chain of the factorisation -- enqueued at
+            // the hand-over they left the main stream dry at every block, and the host is far ahead of the device
+            // again before the first block is due.  Long steps (many tiles, or a group of experts): right here,
+            // behind the step launch, so that the inverse streams start as early as the device allows even under a
+            // slow host (a profiler doubles the host's cost per launch).
+            if (chain_first) forks.push_back({done, b});
+            else if ((rc = fork_inverse_block(g, done, b, nblk, nt - b <= w))) return rc;    // (true: the next block is the last)
             done = b;
             nblk++;
         }
     }
     if (mark && (rc = phase_mark(g, 2))) return rc;         // end of the factorisation on the main stream
-    // The blocks' own launches are enqueued only now, behind the WHOLE chain of the factorisation: enqueued at their
-    // hand-over they cost the main stream a 15-35 us bubble each (the host needs that long for a block's 6-8 launches
-    // and the chain's next ~30-us kernel was not enqueued yet); the host is far ahead of the device either way.
     for (size_t i = 0; i < forks.size(); i++)
-        if ((rc = fork_inverse_block(g, forks[i].a, forks[i].b, (int)i, nt - forks[i].b <= w))) return rc;   // (true: the next block is the last)
+        if ((rc = fork_inverse_block(g, forks[i].a, forks[i].b, (int)i, nt - forks[i].b <= w))) return rc;
     if (w > 0) {
         if ((rc = enqueue_last_block(g, done, nblk))) return rc;      // waits for everything the other streams still do
     } else if (with_inverse) {
