@@ -827,6 +827,45 @@ def test_results_do_not_depend_on_timing(gp_mod, n):
     g.close()
 
 
+@pytest.mark.parametrize("K,n", [(1, 3072), (1, 3200), (1, 2050), (2, 1500), (3, 1100), (2, 2200)])
+def test_hand_over_forms_agree(gp_mod, K, n):
+    """The host enqueues the inverse blocks behind the whole chain of the factorisation up to 24 tile rows in flight and
+    at their hand-over above that, z / alpha run beside the last share of K^-1 above 24 and in line below, and the last
+    block always runs on the factorisation's stream (enqueue_potrf / enqueue_last_block): sizes on both sides of those
+    switches, single matrices and groups, against the same evaluation with everything on one stream after the
+    factorisation (tuning key 3 = 0) -- the two differ only in the order K^-1 is summed in."""
+    from cugp_amd import capi
+    X, y = synth(K * n, d=5, seed=K * n)
+    hp = np.array([0.9, 0.1, -1.3])
+    b = gp_mod.BCM.split(X, y, K) if K > 1 else None
+    g = None
+    if K == 1:
+        g = gp_mod.Covsum(n, 5)
+        g.set_data(X, y)
+
+    def evaluate():
+        if b is not None:
+            b.set_BCM_log_hyperparam(hp)
+            ll, gr, _ = b.loglik_grad()
+            return ll, np.asarray(gr)
+        g.set_loghyperparam(hp + 0.5)                    # (nothing cached from the other form)
+        g.loglik_grad()
+        g.set_loghyperparam(hp)
+        ll, gr = g.loglik_grad()
+        return ll, np.asarray(gr)
+
+    try:
+        ll1, g1 = evaluate()
+        ll1b, g1b = evaluate()
+        capi.check(capi.lib().cugp_set_tuning(3, 0))
+        ll0, g0 = evaluate()
+    finally:
+        capi.check(capi.lib().cugp_set_tuning(3, -1))
+    assert ll1 == ll1b and np.array_equal(g1, g1b)       # reproducible whatever the streams' timing
+    assert abs(ll1 - ll0) <= 1e-11 * abs(ll0) and vec_close(g1, g0, rel=1e-8)
+    (b or g).close()
+
+
 def test_torch_after_the_library_in_one_process():
     """The PyTorch wheel ships its own HIP runtime under the system runtime's library names: whichever is loaded first
     serves the whole process.  capi.lib() therefore loads torch's copy when torch is installed but not imported yet
