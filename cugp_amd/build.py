@@ -13,7 +13,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcugp.so")
 SOURCES = ["kernels.hip", "cugp_capi.cpp", "bcm.cpp", "minimize.cpp"]
-HEADERS = ["kernels.h", os.path.join("..", "..", "include", "cugp.h")]
+HEADERS = ["kernels.h", "group.h"]
+PUBLIC_HEADER = os.path.join(os.path.dirname(HERE), "include", "cugp.h")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-result",
          "-x", "hip"]
@@ -23,7 +24,7 @@ def stale():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [PUBLIC_HEADER, os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

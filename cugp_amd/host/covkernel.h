@@ -4,9 +4,15 @@
 // Same public methods, argument meaning and ownership as the reference: X is an array of row
 // pointers, y a plain array, both caller-owned; compute_gradient_loghyperparam returns a pointer to
 // a function-static double[3] (covkernel.cpp:167); get_loghyperparam returns an internal pointer.
+// The header is C++98-clean: the reference's drivers only compile as -std=gnu++98 (unqualified isnan/isinf,
+// distributed_ver1.cpp:98) and include this file under its reference name.
 // Differences a caller can see:
-//   * no Eigen dependency: set_loghyper_eigen is a template over anything indexable with [0..2]
-//     (Eigen::VectorXd included), the reference's signature being set_loghyper_eigen(Eigen::VectorXd);
+//   * Eigen is optional: when the including translation unit can see the Eigen the reference's own header
+//     includes ("./Eigen/Dense" in cpp_serial_gp/covkernel.h:2, "eigen3/Eigen/Dense" in distributed_gp/covkernel.h:2)
+//     it is included here too -- the reference's drivers get Eigen::VectorXd through covkernel.h
+//     (distributed_ver1.cpp:36) -- and set_loghyper_eigen(Eigen::VectorXd) is the reference's signature; otherwise
+//     set_loghyper_eigen is a template over anything indexable with [0..2].  -DCUGP_HOST_NO_EIGEN switches the
+//     detection off;
 //   * compute_loglikelihood followed by compute_gradient_loghyperparam at the same hyper-parameters
 //     (the order cg_solve uses, covkernel.cpp:500-501) costs ONE factorisation on the GPU, not three;
 //   * compute_squared_dist fills an internal buffer exactly like the reference (tempmatrix2 is
@@ -17,6 +23,19 @@
 #define CUGP_HOST_COVKERNEL_H
 
 #include <vector>
+
+#if !defined(CUGP_HOST_NO_EIGEN) && !defined(CUGP_HOST_HAVE_EIGEN) && defined(__has_include)
+#if __has_include("eigen3/Eigen/Dense")
+#include "eigen3/Eigen/Dense"
+#define CUGP_HOST_HAVE_EIGEN 1
+#elif __has_include("./Eigen/Dense")
+#include "./Eigen/Dense"
+#define CUGP_HOST_HAVE_EIGEN 1
+#elif __has_include(<Eigen/Dense>)
+#include <Eigen/Dense>
+#define CUGP_HOST_HAVE_EIGEN 1
+#endif
+#endif
 
 struct cugp_gp;
 
@@ -31,14 +50,14 @@ private:
     int device;
 
     void bind(double **X, double *y);
+    Covsum(const Covsum &);                  // not copyable (the reference never copies one either:
+    Covsum &operator=(const Covsum &);       // BCM holds std::vector<Covsum *>, BCM.h:7)
 
 public:
     Covsum();
     Covsum(int n, int d);
     Covsum(int n, int d, int device);
     ~Covsum();
-    Covsum(const Covsum &) = delete;
-    Covsum &operator=(const Covsum &) = delete;
 
     double compute_loglikelihood(double **X, double *y);
     double *compute_gradient_loghyperparam(double **X, double *y);
@@ -52,6 +71,13 @@ public:
 
     void compute_test_means_and_variances(double **X, double *y, double **Xtest, double *tmeanvec, double *tvarvec,
                                           int numtest);
+#ifdef CUGP_HOST_HAVE_EIGEN
+    void set_loghyper_eigen(Eigen::VectorXd initval)          // covkernel.h:33, covkernel.cpp:325-329
+    {
+        const double t[3] = {initval[0], initval[1], initval[2]};
+        set_loghyperparam(t);
+    }
+#endif
     template <class Vec3>
     void set_loghyper_eigen(const Vec3 &v)
     {

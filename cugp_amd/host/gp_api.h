@@ -1,14 +1,18 @@
 // gp_api.h -- surface B: the free functions over file-scope state that the reference's GPU drivers
 // forward-declare (cuda_scalingdist/main.cpp:21-53, cg_solver.cpp:14-40), over the C-ABI.
-// Eigen arguments become `const double[3]` (a template keeps Eigen::VectorXd callers compiling).
+// The reference's drivers do not include a header for these: they forward-declare them, so every name here is a
+// real symbol of libcugp_host.so with the reference's signature.  The one exception is
+// `void set_loghyper_eigen(Eigen::VectorXd)` (main.cpp:53,221, cg_solver.cpp:17,262): its mangled name contains
+// the maintainer's Eigen, so it lives in gp_api_eigen.cpp, which the maintainer compiles with that Eigen beside
+// the drivers; callers without Eigen use set_loghyper(const double[3]) or the template below.
 // One GP per process, as in the reference; not re-entrant.
 #ifndef CUGP_HOST_GP_API_H
 #define CUGP_HOST_GP_API_H
 
 #include <string>
 
-extern int numtrain, dimensions;             // cuda_scalingdist/main.cpp:14-16
-extern double *X_host, *labels_host;         // cg_solver.cpp:31-32 (rows read from the last file)
+extern double *X_host, *labels_host;                         // cuda_gp.cu:25,27 (setup allocates N x DIM and N doubles)
+extern double *X_host_buffers[2], *labels_host_buffers[2];   // cuda_gp.cu:26,28 (the background reader's two buffers)
 
 void setup(int numtrain, int dimensions);                                        // cuda_gp.cu:587
 void setup(int numtrain, std::string inputfile, std::string labelfile);          // cuda_src/cuda_gp.cu (older drivers)

@@ -6,8 +6,9 @@
 #include <cstdlib>
 #include <vector>
 
-#include "../../cugp_amd/host/BCM.h"
 #include "../../cugp_amd/host/covkernel.h"
+#include "../../cugp_amd/host/BCM.h"
+#include "../../cugp_amd/host/bcm_solve.h"
 #include "../../cugp_amd/host/gp_api.h"
 
 static void pv(const char *k, const double *v, int n, bool last = false)
@@ -81,7 +82,7 @@ int main(int argc, char **argv)
         poe.compute_BCM_test_means_and_var(X + ntrain, tm.data(), tv.data(), ntest);
         pv("bcm_pred_mean", tm.data(), ntest);
         pv("bcm_pred_var", tv.data(), ntest);
-        cg_solve(poe);
+        cugp_cg_solve(poe);
         double hp[3];
         poe.get_loghyperparam(hp);
         pv("bcm_cg_final_hp", hp, 3);

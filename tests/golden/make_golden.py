@@ -273,6 +273,29 @@ def job(r, name):
         final = r.cg_solve(X, y, HP_DENSE, log)
         out = {"rows": "sine_1024", "n": 1024, "hp0": HP_DENSE, "final_hp": final.tolist(),
                "final_ll": r.loglik(X, y, final), "please_see": parse_please_see(log)}
+    elif name in ("pred4096", "pred8192_dense", "pred8192_ill"):
+        # round 4: predictive mean / variance / NLPP of a single GP at size (covkernel.cpp:105-116,277-323,649-659)
+        if name == "pred4096":
+            d = np.load(os.path.join(HERE, "data_sine_4160.npz"))
+            n, t0r, t1r, hp, rows = 4096, 4096, 4160, HP_DENSE, "sine_4160"
+        else:
+            d = np.load(os.path.join(HERE, "data_siproper_9192.npz"))
+            n, t0r, t1r, rows = 8192, 8192, 8192 + 150, "siproper_9192"
+            hp = HP_DENSE if name.endswith("dense") else HP_ILL
+        X, y = d["X"][:n], d["y"][:n]
+        Xt, yt = d["X"][t0r:t1r], d["y"][t0r:t1r]
+        m, v = r.predict(X, y, hp, Xt)
+        out = {"rows": rows, "n": n, "hp": hp, "test_rows": [t0r, t1r], "pred_mean": m.tolist(),
+               "pred_var": v.tolist(), "nlpp": r.nlpp(yt, m, v)}
+    elif name == "si6000_poe":
+        # round 4: config 4's product-of-experts prediction, 4 x 6000 rows (BCM.cpp:45-83)
+        X, y = _rows("si24000")
+        Xt = np.vstack([X[::600] * 0.9 + 0.05, X[300::1200] * 0.8 - 0.1])
+        yt = np.concatenate([y[::600], y[300::1200]])
+        b = r.bcm(X, y, 4, HP_DENSE)
+        m, v = b.predict(Xt)
+        out = {"K": 4, "rows": [0, 24000], "hp": HP_DENSE, "Xt": Xt.tolist(), "yt": yt.tolist(),
+               "pred_mean": m.tolist(), "pred_var": v.tolist(), "nlpp": b.nlpp(yt, m, v)}
     elif re.match(r"(tail|ill)(\d+)_(ll|grad)$", name):
         # round 3: the ill-conditioned regime.  "tail" = REF's end point on sine rows; "ill" = the dense
         # length scale of HP_DENSE with the tail's amplitude and noise (cond(K) ~ n*sf2/sn2)
@@ -312,6 +335,7 @@ JOBS = (["s10000_grad", "d8192_grad", "s10000_ll"] + ["si6000_%d_grad" % k for k
 JOBS_R3 = ["tail4096_grad", "ill4096_grad", "si24000_bcm16_tail", "tail4096_ll", "ill4096_ll", "cg_sine1024",
            "tail2048_grad", "ill2048_grad", "tail2048_ll", "ill2048_ll",
            "d8192_grad_ill", "d8192_ll_ill", "si24000_bcm16_ill"]           # round 3 (written into golden_r2/ too)
+JOBS_R4 = ["si6000_poe", "pred8192_dense", "pred8192_ill", "pred4096"]      # round 4: prediction at size
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
