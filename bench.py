@@ -13,8 +13,17 @@ reference's cg_solve calls at every probe, covkernel.cpp:500-501).  Inputs are s
 With N ranks every rank owns one N=8192 expert (BCM sharding: experts are independent, weak scaling)
 and the per-evaluation exchange is one all-reduce of K x 4 doubles over RCCL.
 
+The run is made of passes (--passes, default all three, in this order):
+  timed      W warm-up + K evaluations on the DEFAULT path (no per-launch events, no instrumentation): `value`
+  profiled   the same K evaluations with HIP events around the launches of every MFMA kernel on the stream each runs
+             on (cugp_set_profiling 2): the `roofline*` records -- same schedule, the inverse blocks beside the
+             factorisation, so a launch shares the CUs with kernels on the other streams
+  isolated   16 evaluations with the overlap off (every kernel has the chip to itself): `isolated_*`, cholesky_gflops
+tools/make_profiles.sh runs rocprofv3 --kernel-trace --stats once per pass (--passes timed | profiled | isolated), so
+the average duration of a kernel in the CSV named in roofline.dominant_by reproduces roofline.achieved.
+
 Rank 0 prints ONE JSON line; besides the driver's contract it carries
-  roofline        the MFMA kernel with the largest share of kernel time in the timed region (HIP events around its
+  roofline        the MFMA kernel with the largest share of kernel time in the profiled pass (HIP events around its
                   launches on the stream they run on; algorithmic flop / duration against the fp64 MFMA peak)
   roofline_kernels  the same record for every timed kernel, named as rocprofv3 names them
   roofline_trailing_update  k_syrk_step + k_syrk_wide together: the N^3/3 flop of the factorisation's trailing update
@@ -43,7 +52,8 @@ N_METRIC, D_METRIC = 8192, 10
 HP0 = np.array([np.log(3.0), 0.0, np.log(0.1)])      # non-degenerate point: K is dense, cond ~ 1e3
 MFMA_F64_PEAK_TFLOPS = 78.6                          # MI355X dense fp64 matrix peak (spec)
 HBM_PEAK_GBS = 8000.0                                # MI355X HBM3E (MI355X_MICROARCH.md)
-PMC_SUMMARY = "profiles/r03_pmc_summary.json"        # rocprofv3 --pmc passes of this command (tools/pmc.sh)
+ROUND = "r04"
+PMC_SUMMARY = "profiles/%s_pmc_summary.json" % ROUND        # rocprofv3 --pmc passes of this command (tools/pmc.sh)
 # kernels timed by the library at profiling level 2 (cugp_get_kernel_stats_kind): name as rocprofv3 prints it, what it
 # is, and one launch in how many is timed
 KINDS = {0: ("k_syrk_step", "Cholesky near-window trailing update + next diagonal block, K=128 per launch", 16),
@@ -112,6 +122,8 @@ def main():
     ap.add_argument("--overlap", type=int, default=1, help="0: build the inverse after the factorisation on one stream "
                     "(every kernel has the chip to itself: the per-kernel roofline of the whole run is the isolated one "
                     "and no extra pass is made)")
+    ap.add_argument("--passes", default="timed,profiled,isolated", help="comma list of timed, profiled, isolated (see the "
+                    "module docstring); the contract line needs `timed`")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
@@ -162,10 +174,10 @@ def main():
         bcm._allreduce = lambda t: (dist.all_reduce(t, op=dist.ReduceOp.SUM), t)[1]    # the collective, at one rank
     if not bcm.local and strong and K < world:
         pass                                          # more ranks than experts: this rank only takes part in the collectives
-    timed_launches = len(bcm.local) == 1              # per-launch HIP events: the single-expert (metric) workload;
-    for e in bcm.local.values():                      # several experts per GPU share launches and are not timed singly
-        if timed_launches:
-            e.set_profiling(2)
+    passes = [p for p in args.passes.split(",") if p]
+    can_profile = K == world                          # per-launch HIP events: one expert on EVERY rank (the metric workload;
+    for e in bcm.local.values():                      # the same on all ranks: the passes hold barriers); several experts per GPU share launches
+        e.set_profiling(0)
         if not args.overlap:
             e.set_overlap(False)
 
@@ -179,35 +191,57 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    if timed_launches:
-        first_e = next(iter(bcm.local.values()))
-        for kd in KINDS:
-            first_e.kernel_stats(reset=True, kind=kd)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ll, g, _ = step(args.warmup + i)
-    fence()
-    dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
-    if collective:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    def timed_steps(nwarm, nsteps):
+        """nwarm untimed + nsteps timed evaluations; -> (max-over-ranks seconds, last ll, last gradient)"""
+        for i in range(nwarm):
+            step(i)
+        fence()
+        t0_ = time.perf_counter()
+        r_ = (float("nan"), np.full(3, np.nan), None)
+        for i in range(nsteps):
+            r_ = step(nwarm + i)
+        fence()
+        dt_ = time.perf_counter() - t0_
+        tm_ = torch.tensor([dt_], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        if collective:
+            dist.all_reduce(tm_, op=dist.ReduceOp.MAX)
+        return float(tm_.item()), r_[0], r_[1]
 
     first = next(iter(bcm.local.values()), None)      # None: a rank that owns no expert
     empty = {"launches": 0, "sum_ms": 0.0, "flop": 0.0}
-    kst = {kd: (first.kernel_stats(kind=kd) if timed_launches else dict(empty)) for kd in KINDS}
-    ph = first.phase_ms() if timed_launches else {"potrf": float("nan"), "kbuild": float("nan")}
+    nanph = {"potrf": float("nan"), "kbuild": float("nan")}
+
+    # ---- pass 1, timed: the default path, nothing instrumented -> `value`
+    dt, ll, g = float("nan"), float("nan"), np.full(3, np.nan)
+    if "timed" in passes:
+        dt, ll, g = timed_steps(args.warmup, args.steps)
+
+    # ---- pass 2, profiled: the same evaluations with HIP events around the MFMA launches -> roofline*
+    timed_launches = can_profile and "profiled" in passes
+    kst = {kd: dict(empty) for kd in KINDS}
+    ph = dict(nanph)
+    dt_prof = None
+    if timed_launches:
+        first.set_profiling(2)
+        step(0)                                       # event pools, first profiled enqueue
+        for kd in KINDS:
+            first.kernel_stats(reset=True, kind=kd)
+        dt_prof, ll_p, g_p = timed_steps(0, args.steps)
+        kst = {kd: first.kernel_stats(kind=kd) for kd in KINDS}
+        ph = first.phase_ms()
+        if "timed" not in passes:
+            dt, ll, g = dt_prof, ll_p, g_p
     npad = -(-args.n // 128) * 128
 
-    # Outside the timed region: the same kernels with the chip to themselves.  In the timed region the inverse blocks
+    # ---- pass 3, isolated: the same kernels with the chip to themselves.  In the other passes the inverse blocks
     # run beside the factorisation on other streams, so a launch shares the CUs and its duration is not a statement
-    # about the kernel alone; eight more evaluations with the overlap off give that number.
+    # about the kernel alone; sixteen more evaluations with the overlap off give that number.
     iso = iso_ph = None
-    if rank == 0 and len(bcm.local) == 1 and args.overlap and timed_launches:
+    if rank == 0 and can_profile and args.overlap and "isolated" in passes:
+        first.set_profiling(2)
         first.set_overlap(False)
+        first.set_loghyperparam(HP0)
+        first.loglik_grad()
         for kd in KINDS:
             first.kernel_stats(reset=True, kind=kd)
         for i in range(16):                       # level-2 profiling times every 16th step launch, rotating
@@ -216,6 +250,8 @@ def main():
         iso = {kd: first.kernel_stats(kind=kd) for kd in KINDS}
         iso_ph = first.phase_ms()
         first.set_overlap(True)
+    if first is not None and can_profile:
+        first.set_profiling(0)
 
     # prediction (covkernel.cpp:277-323): 1000 test points against the resident model, factor and inverse valid
     predict = None
@@ -251,12 +287,23 @@ def main():
                 sb.set_loghyper(HP0 + 1e-3 * i)
                 sb.loglik_grad()
             fence()
+            sb.reset_timers()
             ts = time.perf_counter()
             for i in range(args.sub_steps):
                 sb.set_loghyper(HP0 + 1e-3 * ((i % 7) - 3))
                 sll, sg, _ = sb.loglik_grad()
             fence()
             sdt = time.perf_counter() - ts
+            # per rank: host-clock ms per evaluation in its own experts (enqueue -> rows in place) and in the exchange
+            # (staging copy + all-reduce + copy back, which also absorbs waiting for the slowest rank)
+            per = torch.tensor([1e3 * sb.t_device / args.sub_steps, 1e3 * sb.t_collective / args.sub_steps],
+                               dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            if collective:
+                allp = [torch.zeros_like(per) for _ in range(world)]
+                dist.all_gather(allp, per)
+            else:
+                allp = [per]
+            allp = [[float(v) for v in t.cpu()] for t in allp]
             tm = torch.tensor([sdt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
             if collective:
                 dist.all_reduce(tm, op=dist.ReduceOp.MAX)
@@ -264,6 +311,7 @@ def main():
             subs[name] = {"experts": Ks, "rows_per_expert": rows, "experts_per_gpu": -(-Ks // world), "n_gpus": world,
                           "steps": args.sub_steps, "ms_per_eval": 1e3 * sdt / args.sub_steps,
                           "evals_per_s": args.sub_steps / sdt, "scaling": "strong", "ll_last": sll,
+                          "device_ms": [round(v[0], 4) for v in allp], "collective_ms": [round(v[1], 4) for v in allp],
                           "eval_tflops_n3": Ks * float(rows) ** 3 / (sdt / args.sub_steps) / 1e12}
             sb.close()
 
@@ -278,12 +326,15 @@ def main():
             "config": {"workload": ("bcm_%dx%d_D%d" % (K, args.n, args.d)) if strong
                        else "gp_loglik_grad_N%d_D%d" % (args.n, args.d), "experts": K,
                        "experts_per_gpu": (K + world - 1) // world if strong else args.experts_per_gpu,
-                       "sharding": "bcm-experts-per-gpu", "overlap": bool(args.overlap) and len(bcm.local) == 1,
-                       "hp": HP0.tolist()},
+                       "sharding": "bcm-experts-per-gpu", "overlap": bool(args.overlap) and can_profile,
+                       "hp": HP0.tolist(), "passes": passes,
+                       "value_from": "timed pass: default path, no per-launch events" if "timed" in passes
+                       else "profiled pass (no timed pass was run)"},
             "cholesky_gflops": (npad ** 3 / 3.0) / ((iso_ph or ph)["potrf"] * 1e-3) / 1e9,   # factorisation alone (overlap off)
             "eval_tflops_n3": (float(args.n) ** 3) * (K if strong else world * args.experts_per_gpu) / world
                               / (dt / args.steps) / 1e12,
             "phase_ms_last": {k: round(v, 4) for k, v in ph.items()},
+            "ms_per_step_profiled": (1e3 * dt_prof / args.steps) if dt_prof else None,
             "ll_last": ll, "grad_last": [float(v) for v in g],
         }
         if predict:
@@ -324,11 +375,15 @@ def main():
                 r["share_of_timed_kernel_time"] = r["est_ms_per_eval"] / tot
             dom = max(recs, key=lambda k: recs[k]["est_ms_per_eval"])
             out["roofline"] = dict(recs[dom])
-            out["roofline"]["dominant_by"] = ("largest share of the MFMA kernels' time in the timed region "
-                                              "(est_ms_per_eval; rocprofv3 --kernel-trace --stats of this command: "
-                                              "profiles/r03_bench_n8192_kernel_stats.csv)")
-            out["roofline"]["note"] = ("achieved/frac: timed region, where a launch shares the CUs with kernels on the "
-                                       "other streams; isolated_*: same kernel, overlap off")
+            out["roofline"]["dominant_by"] = ("largest share of the MFMA kernels' time in the profiled pass "
+                                              "(est_ms_per_eval); rocprofv3 --kernel-trace --stats of that pass alone "
+                                              "(bench.py --passes profiled): profiles/%s_bench_profiled_n8192_kernel_stats.csv, "
+                                              "of the timed pass: profiles/%s_bench_timed_n8192_kernel_stats.csv, of the "
+                                              "isolated pass: profiles/%s_bench_isolated_n8192_kernel_stats.csv"
+                                              % (ROUND, ROUND, ROUND))
+            out["roofline"]["note"] = ("achieved/frac: profiled pass = the timed pass's schedule with HIP events around "
+                                       "the launches, where a launch shares the CUs with kernels on the other streams; "
+                                       "isolated_*: same kernel, overlap off")
             out["roofline"]["whole_evaluation_frac"] = out["eval_tflops_n3"] / MFMA_F64_PEAK_TFLOPS
             out["roofline_kernels"] = recs
             ks, kw = kst[0], kst[1]

@@ -12,6 +12,8 @@ single-process loop of distributed_gp/BCM.cpp:153-198 whatever the number of ran
 The per-expert evaluator is injectable (`expert_factory`) so the sharding / reduction logic can be
 exercised on CPU ranks in the tests; the default builds `cugp_amd.gp.Covsum` handles on the GPU.
 """
+import time
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -63,6 +65,9 @@ class ShardedBCM:
                 e.set_data(X, y)
                 self.local[k] = e
         self.hp = np.zeros(3)
+        # host-clock seconds spent in this rank's evaluations (enqueue -> rows in place) and in the exchange
+        # (staging copy, all-reduce, copy back), summed since reset_timers(): what a multi-GPU run is diagnosed from
+        self.t_device = self.t_collective = 0.0
         if comm_device is None:
             comm_device = torch.device("cuda", device) if (world > 1 and dist.get_backend(group) == "nccl") \
                 else torch.device("cpu")
@@ -96,15 +101,22 @@ class ShardedBCM:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
+    def reset_timers(self):
+        self.t_device = self.t_collective = 0.0
+
     def loglik_grad(self):
         """-> (sum_k LL_k, sum_k grad_k, per-expert LL[K]); one collective of K x 4 doubles."""
+        t0 = time.perf_counter()
         if self._on_device:
             # _send: zero everywhere except this rank's rows, which every evaluation overwrites (the other ranks' rows
             # must be exact zeros in the sum); the collective works on a copy, so nothing has to be cleared or waited
             # for on the host between evaluations
             self._group.loglik_grad_rows_device(self._send.data_ptr(), self.mine)   # returns with the rows in place
+            t1 = time.perf_counter()
             self._rows.copy_(self._send)
             out = self._allreduce(self._rows).cpu().numpy()
+            self.t_device += t1 - t0
+            self.t_collective += time.perf_counter() - t1
             return self._ordered_sum(out)
         rows = np.zeros((self.K, 4))
         if self._group is not None:
@@ -116,8 +128,11 @@ class ShardedBCM:
                 ll, g = self.local[k].fetch()
                 rows[k, 0] = ll
                 rows[k, 1:] = g
+        t1 = time.perf_counter()
         self._rows.copy_(torch.from_numpy(rows))
         out = self._allreduce(self._rows).cpu().numpy()
+        self.t_device += t1 - t0
+        self.t_collective += time.perf_counter() - t1
         return self._ordered_sum(out)
 
     def _ordered_sum(self, out):

@@ -248,22 +248,27 @@ int cugp_bcm_loglik_grad_rows_device(cugp_bcm* b, double* dev_rows, const int* s
     if (rc) return rc;
     DeviceSet& ds = b->sets[0];
     const size_t n = ds.idx.size();
+    // (every error return drains what was enqueued and clears grouped_now, like cugp_bcm_loglik_grad_rows: the next
+    //  evaluation of the handle starts clean instead of failing once with CUGP_ERR_BUSY)
     if (ds.grouped_now) {
         const double* dout = nullptr;
         void* stream = nullptr;
-        if ((rc = cugp_group_device_results(ds.group, &dout, &stream))) return rc;
+        if ((rc = cugp_group_device_results(ds.group, &dout, &stream))) { bcm_drain(b); return rc; }   // (the group is still in flight: drained as a group)
         for (size_t i = 0; i < n; i++)
-            if ((rc = cugp_copy_device_row(dev_rows + 4 * (size_t)slot[ds.idx[i]], dout + 8 * i, stream))) return rc;
+            if ((rc = cugp_copy_device_row(dev_rows + 4 * (size_t)slot[ds.idx[i]], dout + 8 * i, stream))) { bcm_drain(b); return rc; }
         std::vector<double> lk(n), gk3(3 * n);
-        return cugp_group_fetch(ds.group, lk.data(), gk3.data());     // waits for the stream: rows are in place
+        rc = cugp_group_fetch(ds.group, lk.data(), gk3.data());       // waits for the stream: rows are in place
+        ds.grouped_now = false;
+        if (rc) bcm_drain(b);
+        return rc;
     }
     for (size_t i = 0; i < n; i++) {
         cugp_gp* e = b->experts[ds.idx[i]];
-        if ((rc = cugp_copy_result_row(e, dev_rows + 4 * (size_t)slot[ds.idx[i]]))) return rc;
+        if ((rc = cugp_copy_result_row(e, dev_rows + 4 * (size_t)slot[ds.idx[i]]))) { bcm_drain(b); return rc; }
     }
     for (size_t i = 0; i < n; i++) {
         double l, g3[3];
-        if ((rc = cugp_loglik_grad_fetch(b->experts[ds.idx[i]], &l, g3))) return rc;
+        if ((rc = cugp_loglik_grad_fetch(b->experts[ds.idx[i]], &l, g3))) { bcm_drain(b); return rc; }
     }
     return CUGP_OK;
 }

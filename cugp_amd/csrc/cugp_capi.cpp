@@ -481,7 +481,10 @@ double trailing_flop(int nt, int ca, int cb, int kw)
 // with_inverse: L^-1 and K^-1 are built block row by block row on further streams as the rows of L become final.
 int enqueue_continue(cugp_gp* g);
 
-int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false, bool tickets_zeroed = false)
+// zeroed_tickets: the arrival counters a launch already in front of this on the stream has zeroed (record_eval: the
+// covariance build, launch_kbuild's `tickets` argument) -- it must be the very buffer the step launches count in, or
+// the counters are cleared here (a stale counter means a diagonal block factored twice or never).
+int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false, const unsigned* zeroed_tickets = nullptr)
 {
     int rc;
     const int nt = g->nt, ld = g->npad;
@@ -497,7 +500,8 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false, bool tickets
     //  main stream a bubble the ~50-us chain steps could not afford.  With the round-3 chain -- ~32 us per step -- the
     //  fine-grained hand-over wins at every size again: 1500 rows 0.77 -> 0.65 ms, 2 x 1500 rows 0.80 -> 0.73 ms.)
     g->eval_seq++;
-    if (tickets_zeroed) {}                                  // (the covariance build in front of it did that)
+    const unsigned* my_tickets = g->grp ? g->grp->tickets : g->dtickets;
+    if (zeroed_tickets && zeroed_tickets == my_tickets) {}   // (the covariance build in front of it did that)
     else if (g->grp) HIPCHK(hipMemsetAsync(g->grp->tickets, 0, (size_t)g->grp->bt.count * nt * sizeof(unsigned), m));
     else HIPCHK(hipMemsetAsync(g->dtickets, 0, (size_t)nt * sizeof(unsigned), m));
     launch_potf2(g->dA, ld, 0, g->d16, g->d64, g->dlogdet, m, B(g));
@@ -579,11 +583,12 @@ int record_eval(cugp_gp* g, bool want_grad, const HyperScalars* hd)
     hipStream_t s = g->stream;
     if (hd) HIPCHK(hipMemcpyAsync(g->dhs, g->hhs, sizeof(HyperScalars), hipMemcpyHostToDevice, s));
     if ((rc = phase_mark(g, 0))) return rc;
-    launch_kbuild(g->dX, g->n, g->d, g->npad, h, g->dA, false, s, hd, B(g), g->grp ? g->grp->tickets : g->dtickets);
+    unsigned* const tickets = g->grp ? g->grp->tickets : g->dtickets;
+    launch_kbuild(g->dX, g->n, g->d, g->npad, h, g->dA, false, s, hd, B(g), tickets);   // also zeroes the step tickets
     if ((rc = phase_mark(g, 1))) return rc;
     g->vec_early = want_grad;
     g->vec_done = false;
-    rc = enqueue_potrf(g, want_grad, true, true);              // + L^-1 and K^-1, block rows at a time beside it
+    rc = enqueue_potrf(g, want_grad, true, tickets);           // + L^-1 and K^-1, block rows at a time beside it
     g->vec_early = false;
     if (rc) return rc;
     if (want_grad) {

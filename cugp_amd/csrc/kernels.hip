@@ -975,10 +975,12 @@ __device__ __forceinline__ void panel_factor(const PanelLanes& pl, double (&r)[M
     } else if (pl.kind == 2) {
         // my row is column idx of L_jj^-1: the inverse replaces the diagonal tile in LDS (the factor itself goes to
         // global memory from the owner's registers)
-        if (arrive_target > 0) {
-            for (int spin = 0; spin < (1 << 20); spin++)
-                if (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= arrive_target) break;
-        }
+        // (unbounded: the waves counted are co-resident waves of this workgroup, each of which counts itself right
+        //  after its loads -- a bounded wait that fell through would overwrite the tile under a wave still loading it
+        //  and give a silently wrong factor)
+        if (arrive_target > 0)
+            while (__hip_atomic_load(arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < arrive_target)
+                __builtin_amdgcn_s_sleep(1);
 #pragma unroll
         for (int c = 0; c < MT; c++) pl.icol[c * (MT + 1)] = r[c];
     } else if (pl.kind == 0 && gdiag) {                                  // the owner wave: the factor's diagonal tile is final
@@ -1511,6 +1513,13 @@ __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, in
         // publish: wave 0 drains its (agent-scope, write-through) tile stores, then ONE of its lanes draws the
         // ticket (relaxed: the tile is in memory before the ticket, and the last arriver reads the tiles with
         // agent-scope loads that bypass its L1 -- the hand-off form of the CDNA guide's Guideline 16, R1)
+        // This form leans on gfx950 behaviour the HIP memory model does not promise: vmcnt counts stores as well as
+        // loads (no separate store counter) and sc1 stores / loads are coherent across the XCDs' L2s.  EVERY read of
+        // the handed-over block must be one of the agent-scope loads of potf2_body<true>.  The library is built for
+        // gfx950 only (cugp_amd/build.py); another target must not compile this silently:
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "k_syrk_step's fence-free ticket hand-off is validated on gfx950 only: use an acq_rel ticket + agent acquire fence elsewhere"
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (threadIdx.x == 0)
             s_ticket = __hip_atomic_fetch_add(&tickets[kb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

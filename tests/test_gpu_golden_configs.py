@@ -209,3 +209,57 @@ def test_cg_trajectory_sine_1024(gp_mod, sine4160):
     assert abs(final[2] - c["final_hp"][2]) <= 1e-6
     assert abs(g.compute_loglikelihood() - c["final_ll"]) <= 1e-8 * abs(c["final_ll"])
     g.close()
+
+
+# ------------------------------------------------------------------ round 4: predictive mean / variance at size
+def pred_close(a, b):
+    a, b = np.asarray(a, dtype=float), np.asarray(b, dtype=float)
+    return bool(np.all(np.abs(a - b) <= 1e-8 + 1e-8 * np.abs(b)))
+
+
+@pytest.mark.parametrize("name", ["pred4096", "pred8192_dense", "pred8192_ill"])
+def test_prediction_at_size_golden(gp_mod, name):
+    """Covsum::compute_test_means_and_variances + get_negative_log_predprob (covkernel.cpp:105-116,277-323,649-659) of a
+    SINGLE GP at 4096 rows (sine rows 0..4095, test rows 4096..4159: dense hp) and at the metric size (siproper_9192
+    rows 0..8191, 150 test rows from 8192 on -- two 128-row test tiles, the second one ragged -- at the dense and at
+    the ill-conditioned hyper-parameters, cond(K) ~ 1e6).  Expected values: the reference's own code (its K^-1 by
+    Cholesky + substitution sweeps, one GEMV per test point), ~15 min / ~2.5 h each on one core.  The GPU path is
+    k_cross + k_predict_gemm (W = Ks L^-T on MFMA tiles) + k_predict_finish.  1e-8 absolute + 1e-8 relative."""
+    c = job(name)
+    z = np.load(os.path.join(GOLDEN, "data_%s.npz" % c["rows"]))
+    n = c["n"]
+    a, e = c["test_rows"]
+    X, y = np.ascontiguousarray(z["X"][:n]), np.ascontiguousarray(z["y"][:n])
+    Xt, yt = np.ascontiguousarray(z["X"][a:e]), np.ascontiguousarray(z["y"][a:e])
+    g = gp_mod.Covsum(n, X.shape[1])
+    g.set_loghyperparam(c["hp"])
+    m, v = g.compute_test_means_and_variances(X, y, Xt)
+    dm = np.max(np.abs(m - np.array(c["pred_mean"])))
+    dv = np.max(np.abs(v - np.array(c["pred_var"])))
+    print("%s: max |d mean| %.3e, max |d var| %.3e over %d test rows" % (name, dm, dv, e - a))
+    assert pred_close(m, c["pred_mean"]), dm
+    assert pred_close(v, c["pred_var"]), dv
+    nlpp = g.get_negative_log_predprob(yt, m, v)
+    assert abs(nlpp - c["nlpp"]) <= 1e-8 * max(1.0, abs(c["nlpp"])), (nlpp, c["nlpp"])
+    # the same test rows one at a time and in two ragged pieces: the batched products must not depend on the batch
+    m1, v1 = g.compute_test_means_and_variances(None, None, Xt[:1])
+    assert m1[0] == m[0] and v1[0] == v[0]
+    m2, v2 = g.compute_test_means_and_variances(None, None, Xt[37:])
+    assert np.array_equal(m2, m[37:]) and np.array_equal(v2, v[37:])
+    g.close()
+
+
+def test_config4_si6000_poe_prediction_golden(gp_mod, si24000):
+    """Config 4's product-of-experts prediction (BCM::compute_BCM_test_means_and_var, BCM.cpp:45-83): 4 x 6000 rows,
+    50 test points, the reference's in-memory BCM (~3 h of reference time)."""
+    X, y = si24000
+    c = job("si6000_poe")
+    b = gp_mod.BCM.split(X, y, 4)
+    b.set_BCM_log_hyperparam(c["hp"])
+    b.loglik_grad()
+    m, v = b.compute_BCM_test_means_and_var(np.array(c["Xt"]))
+    assert pred_close(m, c["pred_mean"]), np.max(np.abs(m - np.array(c["pred_mean"])))
+    assert pred_close(v, c["pred_var"]), np.max(np.abs(v - np.array(c["pred_var"])))
+    nlpp = b.get_BCM_negative_log_predprob(np.array(c["yt"]), m, v)
+    assert abs(nlpp - c["nlpp"]) <= 1e-8 * max(1.0, abs(c["nlpp"]))
+    b.close()

@@ -347,7 +347,7 @@ def test_graph_replay_matches_launch_by_launch(gp_mod, si128):
     assert np.array_equal(res[0], res[1])
 
 
-@pytest.mark.parametrize("K,n", [(4, 128), (3, 700), (5, 1000)])
+@pytest.mark.parametrize("K,n", [(4, 128), (3, 700), (5, 1000), (16, 24000)])     # (16, 24000): the si24000 16-shard shape
 def test_grouped_experts_equal_single_experts(gp_mod, K, n):
     """The experts of a BCM share launches (blockIdx.y = expert, common padded size): every expert's numbers
     are bit-identical to the same expert evaluated alone (same hand-over blocks of the inverse), for equal and
