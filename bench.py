@@ -63,7 +63,9 @@ KINDS = {0: ("k_syrk_step", "Cholesky near-window trailing update + next diagona
          4: ("k_lauum<4>", "shares of K^-1 = L^-T L^-1, 128x128 output tiles", 4),
          5: ("k_lauum<2>", "shares of K^-1, 64x64 output tiles", 4),
          6: ("k_trtri_level<4>", "doubling inside a block of inverse rows, 128x128 output tiles", 16),
-         7: ("k_trtri_level<2>", "doubling inside a block of inverse rows, 64x64 output tiles", 16)}
+         7: ("k_trtri_level<2>", "doubling inside a block of inverse rows, 64x64 output tiles", 16),
+         8: ("k_trtri_block", "a hand-over block's own inverse in one launch: diagonal tiles + all doubling levels "
+                              "(latency-bound: <= 64 workgroups, stage barriers)", 4)}
 
 
 def synth(n, d, seed):

@@ -51,7 +51,7 @@ constexpr int GRAPH_MAX_TILES = 24;   // evaluations up to 3072 rows are replaye
 constexpr int PROF_STRIDE = 16; // profiling level 2 times every 16th step launch, rotating (an event pair costs ~5 us of device time)
 // kinds of timed launches (cugp_get_kernel_stats_kind): the kernels as rocprofv3 names them
 enum { KIND_STEP = 0, KIND_WIDE = 1, KIND_BORDER4 = 2, KIND_BORDER2 = 3, KIND_LAUUM4 = 4, KIND_LAUUM2 = 5,
-       KIND_LEVEL4 = 6, KIND_LEVEL2 = 7, KIND_COUNT = 8 };
+       KIND_LEVEL4 = 6, KIND_LEVEL2 = 7, KIND_BLOCK = 8, KIND_COUNT = 9 };
 
 // One hardware queue per stream up to 16 (the runtime default is 4): the experts of a BCM on one device each
 // drive their own stream, and 16 experts on 4 queues serialise (5.8 ms vs 4.6 ms per evaluation of 16 x 1500
@@ -65,7 +65,7 @@ struct QueueDefault {
 // set on the lead expert while a group evaluation is being enqueued: every launch then serves all experts
 struct GroupCtx {
     Batch bt;                       // device table of the experts' buffers, expert count
-    unsigned* tickets = nullptr;    // the experts' step tickets, contiguous [k][nt]
+    unsigned* tickets = nullptr;    // the experts' step tickets and block-inverse stage counters, contiguous [k][2 nt]
     double* dout = nullptr;         // results [k][8] on the device ...
     double* hout = nullptr;         // ... and pinned
     bool overlap = false;           // hand the group's inverse blocks to the lead expert's other streams
@@ -83,7 +83,8 @@ struct cugp_gp {
     double *dX = nullptr, *dy = nullptr, *dA = nullptr, *dT = nullptr, *dU = nullptr, *dKinv = nullptr;
     double *dz = nullptr, *dalpha = nullptr, *dw = nullptr, *d16 = nullptr, *dlogdet = nullptr, *dpart = nullptr, *d64 = nullptr;
     double* dout = nullptr;
-    unsigned* dtickets = nullptr;  // one arrival counter per factorisation step (k_syrk_step)
+    unsigned* dtickets = nullptr;  // [0, nt): one arrival counter per factorisation step (k_syrk_step); [nt, 2 nt): the stage
+                                   // counter of the hand-over block that starts at that tile row (k_trtri_block)
     double* hout = nullptr;        // pinned, 8 doubles
     int nblocks_trace = 0;
     double hp[3] = {0, 0, 0};
@@ -113,8 +114,8 @@ struct cugp_gp {
     std::vector<double> kev_flopv; // per pair: algorithmic flop of the launch
     int kev_used = 0;
     unsigned eval_seq = 0;         // factorisations enqueued so far (rotates the launches that get timed)
-    double kst_ms[8] = {}, kst_flop[8] = {};           // folded sums per kernel kind
-    long long kst_launches[8] = {};
+    double kst_ms[KIND_COUNT] = {}, kst_flop[KIND_COUNT] = {};   // folded sums per kernel kind
+    long long kst_launches[KIND_COUNT] = {};
 };
 
 namespace {
@@ -238,6 +239,33 @@ double level_flop(int nt, int s, int step)
     return kt * 2.0 * TILE * TILE * TILE;
 }
 
+// The block's own inverse: T and U of the diagonal block of rows [a, a + wb), on stream o.  One launch (k_trtri_block:
+// diagonal-tile inverses + every doubling level, stage counter tickets[nt + a]) for hand-over blocks; the whole-matrix
+// form (wb > TRTRI_BLOCK_MAX_TILES: large levels want 128x128 tiles and fill the chip) stays launch by launch.
+int enqueue_block_own_inverse(cugp_gp* g, int a, int wb, hipStream_t o)
+{
+    const int ld = g->npad;
+    const bool timed = g->prof >= 2;
+    if (wb <= TRTRI_BLOCK_MAX_TILES) {
+        unsigned* base = g->grp ? g->grp->tickets : g->dtickets;
+        TimedLaunch tl(g, o, timed && ((a / (wb > 0 ? wb : 1)) + (int)g->eval_seq) % 4 == 0);
+        launch_trtri_block(g->dA, g->d64, g->dT, g->dU, ld, a, wb, base + g->nt + a, g->dlogdet, g->nt + a, o, B(g));
+        double fl = 0;
+        for (int s = 1; s < wb; s *= 2) fl += level_flop(wb, s, 1) + level_flop(wb, s, 2);
+        tl.done(KIND_BLOCK, fl);
+        return CUGP_OK;
+    }
+    const size_t off = (size_t)a * TILE * ld + (size_t)a * TILE;
+    launch_trtri_diag(g->dA, ld, a, wb, g->d64, g->dT, g->dU, o, B(g));
+    for (int s = 1; s < wb; s *= 2)
+        for (int step = 1; step <= 2; step++) {
+            TimedLaunch tl(g, o, timed && (a + s + step + (int)g->eval_seq) % 16 == 0);  // small launches: one in sixteen
+            const int wm = launch_trtri_level(g->dA, g->dT, g->dU, ld, wb, s, step, o, B(g), off);
+            if (wm) tl.done(wm == 4 ? KIND_LEVEL4 : KIND_LEVEL2, level_flop(wb, s, step));
+        }
+    return CUGP_OK;
+}
+
 // Inverse quantities of block rows [a, b): T and U = T^T (diagonal-tile inverses, doubling inside the block,
 // bordering against the finished rows [0, a)) and the block's share of K^-1 = T^T T (when Kinv is wanted).
 // The block's own inverse is a chain of small launches; on its own stream `xs` (when given) it runs beside
@@ -248,16 +276,10 @@ int enqueue_inverse_block(cugp_gp* g, int a, int b, bool kinv, hipStream_t x, hi
                           hipStream_t lq = nullptr, hipEvent_t rows_final = nullptr, bool before_last = false)
 {
     const int ld = g->npad, wb = b - a;
-    const size_t off = (size_t)a * TILE * ld + (size_t)a * TILE;
     hipStream_t o = xs ? xs : x;
-    launch_trtri_diag(g->dA, ld, a, wb, g->d64, g->dT, g->dU, o, B(g));
     const bool timed = g->prof >= 2;
-    for (int s = 1; s < wb; s *= 2)
-        for (int step = 1; step <= 2; step++) {
-            TimedLaunch tl(g, o, timed && (a + s + step + (int)g->eval_seq) % 16 == 0);  // small launches: one in sixteen
-            const int wm = launch_trtri_level(g->dA, g->dT, g->dU, ld, wb, s, step, o, B(g), off);
-            if (wm) tl.done(wm == 4 ? KIND_LEVEL4 : KIND_LEVEL2, level_flop(wb, s, step));
-        }
+    int rc0;
+    if ((rc0 = enqueue_block_own_inverse(g, a, wb, o))) return rc0;
     if (xs) {
         HIPCHK(hipEventRecord(own_done, xs));
         HIPCHK(hipStreamWaitEvent(x, own_done, 0));
@@ -324,16 +346,10 @@ int enqueue_inverse_block(cugp_gp* g, int a, int b, bool kinv, hipStream_t x, hi
 int enqueue_last_block(cugp_gp* g, int a, int idx)
 {
     const int nt = g->nt, ld = g->npad, wb = nt - a;
-    const size_t off = (size_t)a * TILE * ld + (size_t)a * TILE;
     hipStream_t m = g->stream;
     const bool timed = g->prof >= 2;
-    launch_trtri_diag(g->dA, ld, a, wb, g->d64, g->dT, g->dU, m, B(g));
-    for (int s = 1; s < wb; s *= 2)
-        for (int step = 1; step <= 2; step++) {
-            TimedLaunch tl(g, m, timed && (a + s + step + (int)g->eval_seq) % 16 == 0);
-            const int wm = launch_trtri_level(g->dA, g->dT, g->dU, ld, wb, s, step, m, B(g), off);
-            if (wm) tl.done(wm == 4 ? KIND_LEVEL4 : KIND_LEVEL2, level_flop(wb, s, step));
-        }
+    int rc0;
+    if ((rc0 = enqueue_block_own_inverse(g, a, wb, m))) return rc0;
     const bool timed2 = timed && ((a / (wb > 0 ? wb : 1)) + (int)g->eval_seq) % 4 == 0;
     HIPCHK(hipStreamWaitEvent(m, g->bev.back(), 0));
     {
@@ -502,8 +518,8 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false, const unsign
     g->eval_seq++;
     const unsigned* my_tickets = g->grp ? g->grp->tickets : g->dtickets;
     if (zeroed_tickets && zeroed_tickets == my_tickets) {}   // (the covariance build in front of it did that)
-    else if (g->grp) HIPCHK(hipMemsetAsync(g->grp->tickets, 0, (size_t)g->grp->bt.count * nt * sizeof(unsigned), m));
-    else HIPCHK(hipMemsetAsync(g->dtickets, 0, (size_t)nt * sizeof(unsigned), m));
+    else if (g->grp) HIPCHK(hipMemsetAsync(g->grp->tickets, 0, (size_t)g->grp->bt.count * 2 * nt * sizeof(unsigned), m));
+    else HIPCHK(hipMemsetAsync(g->dtickets, 0, (size_t)2 * nt * sizeof(unsigned), m));
     launch_potf2(g->dA, ld, 0, g->d16, g->d64, g->dlogdet, m, B(g));
     for (int kb = 0; kb + 1 < nt; kb++) {
         launch_trsm_inv64(g->dA, g->d64, ld, kb, nt, m, B(g));
@@ -677,6 +693,7 @@ int enqueue_continue(cugp_gp* g)
     const HyperScalars h = scalars(g);
     hipStream_t s = g->stream;
     g->inverse_valid = false;
+    HIPCHK(hipMemsetAsync(g->dtickets + g->nt, 0, (size_t)g->nt * sizeof(unsigned), s));     // k_trtri_block's stage counters
     if ((rc = enqueue_inverse_block(g, 0, g->nt, true, s, nullptr, nullptr))) return rc;
     launch_trmv_lower(g->dT, g->npad, g->npad, g->dy, g->dz, s);
     launch_trmv_upper(g->dU, g->npad, g->npad, g->dz, g->dalpha, s);
@@ -745,10 +762,19 @@ int cugp_create_padded(int n, int d, int device, int npad_min, cugp_gp** out)
     hipError_t e = hipSetDevice(device);
     // default priority everywhere: prioritised streams share few hardware queues, which serialises the
     // experts of a BCM evaluated on one device
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->aux, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->aux2, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&g->lq, hipStreamNonBlocking);
+    // (TUNE_STREAM_PRIO, an A/B hook: the factorisation's stream at the highest and / or the inverse streams at the
+    //  lowest priority)
+    int plo = 0, phi = 0;
+    if (e == hipSuccess && g_tune[TUNE_STREAM_PRIO] != 0) e = hipDeviceGetStreamPriorityRange(&plo, &phi);
+    const int pmain = (g_tune[TUNE_STREAM_PRIO] & 1) ? phi : 0, pinv = (g_tune[TUNE_STREAM_PRIO] & 2) ? plo : 0;
+    auto mkstream = [&](hipStream_t* s, int prio) {
+        return g_tune[TUNE_STREAM_PRIO] != 0 ? hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio)
+                                             : hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    };
+    if (e == hipSuccess) e = mkstream(&g->stream, pmain);
+    if (e == hipSuccess) e = mkstream(&g->aux, pinv);
+    if (e == hipSuccess) e = mkstream(&g->aux2, pinv);
+    if (e == hipSuccess) e = mkstream(&g->lq, pinv);
     for (std::vector<hipEvent_t>* v : {&g->bev, &g->oev, &g->lev}) {
         v->assign((size_t)g->nt + 2, nullptr);
         for (size_t i = 0; i < v->size() && e == hipSuccess; i++) e = hipEventCreateWithFlags(&(*v)[i], hipEventDisableTiming);
@@ -763,7 +789,7 @@ int cugp_create_padded(int n, int d, int device, int npad_min, cugp_gp** out)
     if (e == hipSuccess) e = hipMalloc((void**)&g->dlogdet, (size_t)g->nt * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&g->dpart, (size_t)g->nblocks_trace * 3 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&g->dout, 8 * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&g->dtickets, (size_t)g->nt * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc((void**)&g->dtickets, (size_t)2 * g->nt * sizeof(unsigned));
     if (e == hipSuccess) e = hipHostMalloc((void**)&g->hout, 8 * sizeof(double), hipHostMallocDefault);
     if (e == hipSuccess) e = hipHostMalloc((void**)&g->hhs, sizeof(HyperScalars), hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc((void**)&g->dhs, sizeof(HyperScalars));
@@ -1442,7 +1468,7 @@ int cugp_group_create(cugp_gp* const* experts, int k, cugp_group** out)
     const int nt = experts[0]->nt;
     hipError_t e = hipSetDevice(experts[0]->device);
     if (e == hipSuccess) e = hipMalloc((void**)&gr->dtab, (size_t)k * sizeof(ExpertPtrs));
-    if (e == hipSuccess) e = hipMalloc((void**)&gr->ctx.tickets, (size_t)k * nt * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc((void**)&gr->ctx.tickets, (size_t)k * 2 * nt * sizeof(unsigned));
     if (e == hipSuccess) e = hipMalloc((void**)&gr->ctx.dout, (size_t)k * 8 * sizeof(double));
     if (e == hipSuccess) e = hipHostMalloc((void**)&gr->ctx.hout, (size_t)k * 8 * sizeof(double), hipHostMallocDefault);
     if (e != hipSuccess) {
@@ -1503,7 +1529,7 @@ int cugp_group_enqueue(cugp_group* gr, int want_grad)
             cugp_gp* e = gr->experts[i];
             tab[i] = ExpertPtrs{e->dA, e->dT, e->dU, e->dKinv, e->d16, e->d64, e->dlogdet, e->dy, e->dz, e->dalpha,
                                 e->dw, e->dpart, gr->ctx.dout + (size_t)i * 8, e->dX,
-                                gr->ctx.tickets + (size_t)i * nt, e->n};
+                                gr->ctx.tickets + (size_t)i * 2 * nt, e->n};
         }
         HIPCHK(hipStreamSynchronize(lead->stream));           // a captured graph may still be reading the old table
         HIPCHK(hipMemcpy(gr->dtab, tab.data(), tab.size() * sizeof(ExpertPtrs), hipMemcpyHostToDevice));

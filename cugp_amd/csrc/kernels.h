@@ -24,7 +24,8 @@ enum { TUNE_LAUUM_WM2_MAX = 0,   // K^-1 product: use 64x64 tiles when there are
        TUNE_STEP_STREAM = 12,    // two-speed step kernel: non-temporal accesses to the C tiles (1) or plain ones (0)
        TUNE_SPLIT_REM_MAX = 13,  // uniform-K launches (block-wise K^-1 share, bordering, wide update): a last round of at most this many tiles runs as 64x64 quarters
        TUNE_STEP_QUARTER_MAX = 14, // step kernel: launches of at most this many 64x64 workgroups run ALL their tiles as quarters (chain-bound tail)
-       TUNE_COUNT = 15 };
+       TUNE_STREAM_PRIO = 15,    // read when a handle is created: bit 0 = the factorisation's stream at the highest priority, bit 1 = the inverse streams at the lowest (default 0: prioritised streams serialised grouped experts in round 3)
+       TUNE_COUNT = 16 };
 extern int g_tune[TUNE_COUNT];
 
 struct HyperScalars;
@@ -67,6 +68,12 @@ void launch_potf2(double* A, int ld, int kb, double* d16, double* d64, double* l
 void launch_trsm_inv64(double* A, const double* d64, int ld, int kb, int nt, hipStream_t s, Batch bt = {});   // 3-phase, 64x64 inverses
 void launch_trtri_diag(const double* A, int ld, int kb, int nblocks, const double* d64, double* T, double* U,
                        hipStream_t s, Batch bt = {});
+// inverse of the hand-over block of rows [a, a + wb) in one launch: diagonal-tile inverses + every doubling level inside
+// the block (k_trtri_block; wb <= TRTRI_BLOCK_MAX_TILES).  ctr: the block's stage counter (zero before the launch; batched:
+// tickets[ctr_off] of every expert); poison: log-determinant shares (entry a becomes NaN if a stage wait ran out)
+constexpr int TRTRI_BLOCK_MAX_TILES = 16;
+int launch_trtri_block(const double* L, const double* d64, double* T, double* U, int ld, int a, int wb, unsigned* ctr,
+                       double* poison, int ctr_off, hipStream_t s, Batch bt = {});
 // trailing update of step kb fused with the factorisation of diagonal block kb+1 (tickets[kb] must be 0)
 // wcol > 0: only the tile columns [kb+1, kb+1+wcol) (two-speed form: the near window)
 void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* d64, double* logdet_part,

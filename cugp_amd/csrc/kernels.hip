@@ -46,6 +46,42 @@ __device__ __forceinline__ T* GP(T* p)
     return (T*)(__attribute__((address_space(1))) T*)(unsigned long long)p;
 }
 
+// Diagnostic build only (tools/wgtimes.hip, -DCUGP_WGTIMES): every workgroup of the kernels below leaves
+// {kind | param << 8, start, end} (s_memrealtime, 100 MHz) in a side buffer -- when the workgroups of a launch were
+// dispatched and how long each ran, i.e. whether a launch that took long beside other streams WAITED for workgroup
+// slots or RAN slowly.  Nothing of it exists in the product build.
+#ifdef CUGP_WGTIMES
+constexpr unsigned WGT_CAP = 1u << 19;
+__device__ unsigned long long g_wgt[3 * WGT_CAP];
+__device__ unsigned g_wgt_n;
+struct WgTimer {
+    unsigned long long t0, tag;
+    __device__ __forceinline__ WgTimer(int kind, int param) : t0(__builtin_amdgcn_s_memrealtime()), tag((unsigned long long)kind | (unsigned long long)param << 8) {}
+    __device__ __forceinline__ ~WgTimer()
+    {
+        if (threadIdx.x == 0) {
+            const unsigned i = atomicAdd(&g_wgt_n, 1u);
+            if (i < WGT_CAP) { g_wgt[3 * i] = tag; g_wgt[3 * i + 1] = t0; g_wgt[3 * i + 2] = __builtin_amdgcn_s_memrealtime(); }
+        }
+    }
+};
+#define WGT(name, kind, param) WgTimer name(kind, param)
+void wgt_reset() { const unsigned z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_wgt_n), &z, sizeof z); }
+unsigned wgt_fetch(unsigned long long* out, unsigned cap)
+{
+    unsigned n = 0;
+    (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_wgt_n), sizeof n);
+    if (n > WGT_CAP) n = WGT_CAP;
+    if (n > cap) n = cap;
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgt), (size_t)n * 24);
+    return n;
+}
+#else
+#define WGT(name, kind, param)
+#endif
+enum { WGT_TRSM = 0, WGT_DIAGUPD = 1, WGT_POTF2 = 2, WGT_STEPTILE = 3, WGT_BORDER = 4, WGT_LAUUM = 5, WGT_LEVEL = 6,
+       WGT_TRTRI_DIAG = 7, WGT_WIDE = 8 };
+
 // ------------------------------------------------------------------------------------------
 // fp64 MFMA tile product
 // ------------------------------------------------------------------------------------------
@@ -352,6 +388,7 @@ __global__ __launch_bounds__(256, 2) void k_lauum(const double* __restrict__ U, 
 {
     if (bt) { U = GP(bt[blockIdx.y].U); Kinv = GP(bt[blockIdx.y].Kinv); }
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    WGT(wgt_, WGT_LAUUM, a);
     if (WM == 2) {
         lauum_tile<2>(U, Kinv, ld, a, w, blockIdx.x >> 2, blockIdx.x & 3, smem);
     } else if ((int)blockIdx.x < nfull) {
@@ -392,18 +429,11 @@ __device__ __forceinline__ void trtri_tile(const double* __restrict__ L, double*
     }
 }
 
-// one level of recursive doubling: all pairs of s-tile blocks at once
+// one tile (blk) / sub-tile (sub) of one level of recursive doubling over nt tiles: all pairs of s-tile blocks
 template <int WM>
-__global__ __launch_bounds__(256, 2) void k_trtri_level(const double* __restrict__ L, double* __restrict__ T,
-                                                        double* __restrict__ U, int ld, int nt, int s, int step,
-                                                        size_t off, const ExpertPtrs* __restrict__ bt)
+__device__ __forceinline__ void level_item(const double* __restrict__ L, double* __restrict__ T, double* __restrict__ U,
+                                           int ld, int nt, int s, int step, int blk, int sub, char* smem)
 {
-    // off: element offset of the diagonal sub-matrix the level works on (a block of inverse rows)
-    if (bt) { L = GP(bt[blockIdx.y].A); T = GP(bt[blockIdx.y].T); U = GP(bt[blockIdx.y].U); }
-    L += off; T += off; U += off;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int SUB = 4 / WM;
-    const int blk = blockIdx.x / (SUB * SUB), sub = blockIdx.x % (SUB * SUB);
     const int npairs = (nt + 2 * s - 1) / (2 * s);      // last one may have a short (or empty) B
     int p = blk / (s * s);
     if (p > npairs - 1) p = npairs - 1;
@@ -418,6 +448,33 @@ __global__ __launch_bounds__(256, 2) void k_trtri_level(const double* __restrict
     const int ib = (step == 1) ? rem % sb : sb - 1 - rem / s;
     const int tj = a0 + ja, ti = b0 + ib;
     trtri_tile<WM>(L, T, U, ld, tj, ti, step, step == 1 ? tj : b0, step == 1 ? b0 : ti + 1, false, sub, smem);
+}
+
+// tiles |A| x |B| of one level over nt tiles (pairs p = 0.. : A = [2ps, 2ps+s), B = [2ps+s, min(2ps+2s, nt)))
+__host__ __device__ inline int level_tiles(int nt, int s)
+{
+    int tiles = 0;
+    for (int a0 = 0; a0 + s < nt; a0 += 2 * s) {
+        int sb = nt - (a0 + s);
+        if (sb > s) sb = s;
+        tiles += s * sb;
+    }
+    return tiles;
+}
+
+// one level of recursive doubling: all pairs of s-tile blocks at once
+template <int WM>
+__global__ __launch_bounds__(256, 2) void k_trtri_level(const double* __restrict__ L, double* __restrict__ T,
+                                                        double* __restrict__ U, int ld, int nt, int s, int step,
+                                                        size_t off, const ExpertPtrs* __restrict__ bt)
+{
+    // off: element offset of the diagonal sub-matrix the level works on (a block of inverse rows)
+    if (bt) { L = GP(bt[blockIdx.y].A); T = GP(bt[blockIdx.y].T); U = GP(bt[blockIdx.y].U); }
+    L += off; T += off; U += off;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    WGT(wgt_, WGT_LEVEL, s * 2 + step);
+    constexpr int SUB = 4 / WM;
+    level_item<WM>(L, T, U, ld, nt, s, step, blockIdx.x / (SUB * SUB), blockIdx.x % (SUB * SUB), smem);
 }
 
 // bordering: rows B = [a, a+w) of the inverse from the finished leading block A = [0, a) and B's own
@@ -446,6 +503,7 @@ __global__ __launch_bounds__(256, 2) void k_trtri_border(const double* __restric
 {
     if (bt) { L = GP(bt[blockIdx.y].A); T = GP(bt[blockIdx.y].T); U = GP(bt[blockIdx.y].U); }
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    WGT(wgt_, WGT_BORDER, a * 4 + step);
     if (WM == 2) {
         border_tile<2>(L, T, U, ld, a, w, step, c0, c1, blockIdx.x >> 2, blockIdx.x & 3, smem);
     } else if ((int)blockIdx.x < nfull) {
@@ -523,6 +581,7 @@ __global__ __launch_bounds__(512) void k_trsm_inv64(double* __restrict__ A, cons
     double* Sc = Sb + MT * TRSM_SS;                     // half sums of the waves h = 1: [w][r][lane]
     double* X0 = Sc + 4 * 4 * 64;                       // X0^T tiles as B operands: [kt][r][lane]
     double* Z1 = X0 + 4 * 4 * 64;
+    WGT(wgt_, WGT_TRSM, kb);
     __builtin_amdgcn_s_setprio(3);                      // on the factorisation's serial chain (see k_syrk_step)
     const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int w = wv & 3, h = wv >> 2, c = lane & 15, g = lane >> 4;
@@ -705,8 +764,9 @@ __global__ __launch_bounds__(256) void k_build(const double* __restrict__ X, int
     }
     // tickets (when given): the factorisation's per-step arrival counters, zeroed here instead of by a memset node in
     // front of the factorisation (one launch boundary less on a chain that small matrices are bound by)
+    // (2 per tile row: [0, nt) the step tickets of k_syrk_step, [nt, 2 nt) the stage counters of k_trtri_block)
     if (tickets && blockIdx.x == 0)
-        for (int i = threadIdx.x; i < npad / TILE; i += 256) tickets[i] = 0u;
+        for (int i = threadIdx.x; i < 2 * (npad / TILE); i += 256) tickets[i] = 0u;
     const HyperScalars h = hd ? *hd : h_arg;
     __shared__ double xs[KT][DC + 1], ys[KT][DC + 1];
     int ti, tj;
@@ -1509,6 +1569,7 @@ __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, in
         // the factorisation's serial chain: win instruction issue over the product waves sharing the SIMD
         // (this launch's own tiles and the inverse blocks running on the other streams)
         __builtin_amdgcn_s_setprio(3);
+        WGT(wgt_, WGT_DIAGUPD, kb);
         diag_update_tile(A, ld, kb, bid, sm);
         // publish: wave 0 drains its (agent-scope, write-through) tile stores, then ONE of its lanes draws the
         // ticket (relaxed: the tile is in memory before the ticket, and the last arriver reads the tiles with
@@ -1528,6 +1589,7 @@ __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, in
         // (the last arriver reads the 36 micro tiles with agent-scope loads: potf2_body<true>, no acquire fence)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int kn = kb + 1;
+        WGT(wgt2_, WGT_POTF2, kb);
         potf2_body<true>(A + (size_t)kn * TILE * ld + kn * TILE, ld, d16 + (size_t)kn * NMT * (MT * MT),
                    d64 + (size_t)kn * 8192, logdet_part + kn, sm, red);
         return;
@@ -1537,6 +1599,7 @@ __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, in
     // Regular tiles: `nfull` of them as 128x128 workgroups; the rest (a partial last round that would
     // leave most of the chip idle for a whole tile time) as four 64x64 workgroups each.
     __builtin_amdgcn_s_setprio(1);                      // ahead of the inverse-block products (priority 0)
+    WGT(wgt_, WGT_STEPTILE, kb);
     const int x = bid - NDIAGWG;
     if (x < nfull) {
         // Workgroups are dealt round-robin over the 8 XCDs (private L2 each): give every XCD one contiguous
@@ -1578,6 +1641,7 @@ __global__ __launch_bounds__(256, 2) void k_syrk_wide(double* __restrict__ A, in
     if (bt) A = GP(bt[blockIdx.y].A);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __builtin_amdgcn_s_setprio(1);
+    WGT(wgt_, WGT_WIDE, k0);
     if ((int)blockIdx.x >= nfull) {
         // the last, partly empty round of the launch as 64x64 quarters (split_round)
         const int y = blockIdx.x - nfull;
@@ -1608,14 +1672,11 @@ __global__ __launch_bounds__(256, 2) void k_syrk_wide(double* __restrict__ A, in
 // step, T10 = -T11 (L10 T00), on 16x16 micro tiles: wave = micro-tile column of T10); writes T (lower, zeros
 // above) and U = T^T (upper, zeros below).  blockIdx.x = block offset from kb.  ~6 us (the blocked
 // substitution from the 16x16 inverses it replaces took 92 us -- 10 % of a 1500-row evaluation).
-__global__ __launch_bounds__(256) void k_trtri_diag(const double* __restrict__ A, int ld, int kb,
-                                                    const double* __restrict__ d64, double* __restrict__ T,
-                                                    double* __restrict__ U, const ExpertPtrs* __restrict__ bt)
+__device__ __forceinline__ void trtri_diag_body(const double* __restrict__ A, int ld, int b,
+                                                const double* __restrict__ d64, double* __restrict__ T,
+                                                double* __restrict__ U, double* __restrict__ sm)
 {
-    if (bt) { A = GP(bt[blockIdx.y].A); d64 = GP(bt[blockIdx.y].d64); T = GP(bt[blockIdx.y].T); U = GP(bt[blockIdx.y].U); }
-    extern __shared__ __attribute__((aligned(16))) double sm[];       // 36 lower micro tiles, as potf2_body
     const int t = threadIdx.x, wave = t >> 6;
-    const int b = kb + blockIdx.x;
     const double* Ab = A + (size_t)b * TILE * ld + b * TILE;
     const double* T00 = d64 + (size_t)b * 8192;
     const double* T11 = T00 + 4096;
@@ -1667,6 +1728,87 @@ __global__ __launch_bounds__(256) void k_trtri_diag(const double* __restrict__ A
         Tb[(size_t)r * ld + c] = bc <= br ? sm[mt_off(br, bc) + (r & 15) * (MT + 1) + (c & 15)] : 0.0;
         Ub[(size_t)r * ld + c] = br <= bc ? sm[mt_off(bc, br) + (c & 15) * (MT + 1) + (r & 15)] : 0.0;   // T(c,r)
     }
+}
+
+__global__ __launch_bounds__(256) void k_trtri_diag(const double* __restrict__ A, int ld, int kb,
+                                                    const double* __restrict__ d64, double* __restrict__ T,
+                                                    double* __restrict__ U, const ExpertPtrs* __restrict__ bt)
+{
+    if (bt) { A = GP(bt[blockIdx.y].A); d64 = GP(bt[blockIdx.y].d64); T = GP(bt[blockIdx.y].T); U = GP(bt[blockIdx.y].U); }
+    extern __shared__ __attribute__((aligned(16))) double sm[];       // 36 lower micro tiles, as potf2_body
+    WGT(wgt_, WGT_TRTRI_DIAG, kb);
+    trtri_diag_body(A, ld, kb + blockIdx.x, d64, T, U, sm);
+}
+
+// ------------------------------------------------------------------------------------------
+// The whole inverse of ONE hand-over block of rows [a, a + wb) -- the 128x128 inverses of its diagonal tiles and every
+// level of the recursive doubling inside the block -- in ONE launch: what k_trtri_diag + 2 log2(wb) launches of
+// k_trtri_level<2> did (at N = 8192, wb = 4: five launches of 2-16 workgroups, 15-45 us apiece while the big products of
+// the other streams hold the chip; 80 of the evaluation's 260 launches).  A small persistent grid (<= 64 workgroups)
+// walks the stages; between two stages every workgroup arrives at a monotonic agent-scope counter and waits for the
+// others (release fence -> add ... poll -> acquire fence: the safe forms of the CDNA guide's barrier-counter row).
+// The same tile code (trtri_diag_body, level_item<2>) in the same per-element order: bit-identical to the launches it
+// replaces.  The grid is far below one workgroup per CU, the workgroups of a launch are dispatched in order, and what
+// holds the other slots always ends without waiting for this launch -- so the waiting is deadlock-free; it is BOUNDED
+// all the same (~seconds), and a wait that ran out poisons the block's log-determinant share (the evaluation comes
+// back NaN instead of hanging the device).
+// ------------------------------------------------------------------------------------------
+constexpr int TRTRI_BLOCK_LDS = TRTRI_LDS > Geo<2>::LDS ? TRTRI_LDS : Geo<2>::LDS;
+constexpr int TRTRI_BLOCK_MAXWG = 64;
+
+__device__ __forceinline__ bool stage_barrier(unsigned* __restrict__ ctr, unsigned target)
+{
+    __shared__ int s_ok;
+    __syncthreads();                                     // every wave's stores of the stage are issued and drained
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the compiler may drop the wait behind the write-back)
+        __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 0;
+        for (unsigned spin = 0; spin < (1u << 21); spin++) {
+            if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_ok = ok;
+    }
+    __syncthreads();
+    return s_ok != 0;
+}
+
+__global__ __launch_bounds__(256, 2) void k_trtri_block(const double* __restrict__ L, const double* __restrict__ d64,
+                                                        double* __restrict__ T, double* __restrict__ U, int ld, int a,
+                                                        int wb, unsigned* __restrict__ ctr, double* __restrict__ poison,
+                                                        int ctr_off, const ExpertPtrs* __restrict__ bt)
+{
+    if (bt) {
+        const ExpertPtrs& e = bt[blockIdx.y];
+        L = GP(e.A); d64 = GP(e.d64); T = GP(e.T); U = GP(e.U); ctr = GP(e.tickets) + ctr_off; poison = GP(e.logdet);
+    }
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    WGT(wgt_, WGT_TRTRI_DIAG, a);
+    const int G = gridDim.x, wg = blockIdx.x;
+    for (int b = wg; b < wb; b += G) {
+        if (b != wg) __syncthreads();                    // (the body's LDS image is reused)
+        trtri_diag_body(L, ld, a + b, d64, T, U, (double*)smem);
+    }
+    const size_t off = (size_t)a * TILE * ld + (size_t)a * TILE;
+    const double* Lb = L + off;
+    double* Tb = T + off;
+    double* Ub = U + off;
+    unsigned stage = 0;
+    bool ok = true;
+    for (int s = 1; s < wb; s *= 2)
+        for (int step = 1; step <= 2; step++) {
+            ok = stage_barrier(ctr, (unsigned)G * ++stage) && ok;
+            const int items = level_tiles(wb, s) * 4;
+            for (int it = wg; it < items; it += G) {
+                if (it != wg) __syncthreads();           // (the transposed store of the item before still reads its LDS image)
+                level_item<2>(Lb, Tb, Ub, ld, wb, s, step, it >> 2, it & 3, smem);
+            }
+        }
+    if (!ok && threadIdx.x == 0) poison[a] = __builtin_nan("");
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1895,7 +2037,7 @@ __global__ __launch_bounds__(256) void k_predict_finish(const double* __restrict
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-int g_tune[TUNE_COUNT] = {768, 1200, 384, -1, 511, 1, 1, 1 << 20, 16, 500, 32, 1, 1, 256, 1536};   // defaults chosen by interleaved A/B runs (tools/ab.py)
+int g_tune[TUNE_COUNT] = {768, 1200, 384, -1, 511, 1, 1, 1 << 20, 16, 500, 32, 1, 1, 256, 1536, 0};   // defaults chosen by interleaved A/B runs (tools/ab.py)
 
 static inline int tri_count(int n) { return n * (n + 1) / 2; }
 
@@ -1941,6 +2083,7 @@ static void set_big_lds()
                            (const void*)k_predict_gemm, (const void*)k_test_gemm};
     for (const void* f : gemm4) attr(f, GEMM_LDS);
     attr((const void*)k_trtri_diag, TRTRI_LDS);
+    attr((const void*)k_trtri_block, TRTRI_BLOCK_LDS);
     attr((const void*)k_trsm_inv64, TRSM_LDS);
     if (e != hipSuccess) { g_attr_err = e; return; }
     g_attr_done |= 1ull << dev;
@@ -1967,6 +2110,22 @@ void launch_trtri_diag(const double* A, int ld, int kb, int nblocks, const doubl
 {
     set_big_lds();
     hipLaunchKernelGGL(k_trtri_diag, dim3(nblocks, bt.count), dim3(256), TRTRI_LDS, s, A, ld, kb, d64, T, U, bt.tab);
+}
+
+int launch_trtri_block(const double* L, const double* d64, double* T, double* U, int ld, int a, int wb, unsigned* ctr,
+                       double* poison, int ctr_off, hipStream_t s, Batch bt)
+{
+    if (wb <= 0) return 0;
+    set_big_lds();
+    int G = wb;                                           // workgroups: the widest stage, one item each (<= 64)
+    for (int sl = 1; sl < wb; sl *= 2) {
+        const int items = level_tiles(wb, sl) * 4;
+        if (items > G) G = items;
+    }
+    if (G > TRTRI_BLOCK_MAXWG) G = TRTRI_BLOCK_MAXWG;
+    hipLaunchKernelGGL(k_trtri_block, dim3(G, bt.count), dim3(256), TRTRI_BLOCK_LDS, s, L, d64, T, U, ld, a, wb, ctr,
+                       poison, ctr_off, bt.tab);
+    return G;
 }
 
 // A launch of `tiles` uniform-ish 128x128 tiles fills the 512 workgroup slots round by round; a last round that is

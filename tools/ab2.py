@@ -17,7 +17,7 @@ import cugp_amd.gp as gp                                  # noqa: E402
 from cugp_amd import capi                                 # noqa: E402
 from conftest import synth                                # noqa: E402
 
-DEFAULT = {0: 768, 1: 1200, 2: 384, 3: -1, 4: 511, 5: 1, 6: 1, 7: 1 << 20, 8: 16, 9: 500, 10: 32, 11: 1, 12: 1, 13: 256, 14: 1536}
+DEFAULT = {0: 768, 1: 1200, 2: 384, 3: -1, 4: 511, 5: 1, 6: 1, 7: 1 << 20, 8: 16, 9: 500, 10: 32, 11: 1, 12: 1, 13: 256, 14: 1536, 15: 0}
 n = int(sys.argv[1])
 names = sys.argv[2:] or ["base"]
 variants = [{} if a == "base" else dict((int(k), int(v)) for k, v in (kv.split("=") for kv in a.split(","))) for a in names]
@@ -33,7 +33,8 @@ def apply(var):
 X, y = synth(n)
 g = gp.Covsum(n, 10)
 g.set_data(X, y)
-g.set_profiling(1)
+PROF = int(os.environ.get('AB_PROF', '1'))   # 0: the default path (wall clock only)
+g.set_profiling(PROF)
 hp = np.array([np.log(3.0), 0.0, np.log(0.1)])
 res = [dict(wall=[], potrf=[], total=[], la0=[], la3=[]) for _ in variants]
 vals = [None] * len(variants)
@@ -47,7 +48,7 @@ for rnd, vi in order:
     t0 = time.perf_counter()
     ll, gr = g.loglik_grad()
     t1 = time.perf_counter()
-    ph = g.phase_ms()
+    ph = g.phase_ms() if PROF else {'potrf': float('nan'), 'total': float('nan')}
     if rnd < 0:
         continue                                  # warm-up after a switch (sequential mode)
     if rnd == 0:
