@@ -47,21 +47,24 @@ __device__ __forceinline__ T* GP(T* p)
 }
 
 // Diagnostic build only (tools/wgtimes.hip, -DCUGP_WGTIMES): every workgroup of the kernels below leaves
-// {kind | param << 8, start, end} (s_memrealtime, 100 MHz) in a side buffer -- when the workgroups of a launch were
+// {kind | param << 8, start, end (s_memrealtime, 100 MHz), shader cycles lived (s_memtime)} in a side buffer -- when the workgroups of a launch were
 // dispatched and how long each ran, i.e. whether a launch that took long beside other streams WAITED for workgroup
 // slots or RAN slowly.  Nothing of it exists in the product build.
 #ifdef CUGP_WGTIMES
 constexpr unsigned WGT_CAP = 1u << 19;
-__device__ unsigned long long g_wgt[3 * WGT_CAP];
+__device__ unsigned long long g_wgt[4 * WGT_CAP];
 __device__ unsigned g_wgt_n;
 struct WgTimer {
-    unsigned long long t0, tag;
-    __device__ __forceinline__ WgTimer(int kind, int param) : t0(__builtin_amdgcn_s_memrealtime()), tag((unsigned long long)kind | (unsigned long long)param << 8) {}
+    unsigned long long t0, c0, tag;
+    __device__ __forceinline__ WgTimer(int kind, int param) : t0(__builtin_amdgcn_s_memrealtime()), c0(__builtin_amdgcn_s_memtime()), tag((unsigned long long)kind | (unsigned long long)param << 8) {}
     __device__ __forceinline__ ~WgTimer()
     {
         if (threadIdx.x == 0) {
             const unsigned i = atomicAdd(&g_wgt_n, 1u);
-            if (i < WGT_CAP) { g_wgt[3 * i] = tag; g_wgt[3 * i + 1] = t0; g_wgt[3 * i + 2] = __builtin_amdgcn_s_memrealtime(); }
+            if (i < WGT_CAP) {
+                g_wgt[4 * i] = tag; g_wgt[4 * i + 1] = t0; g_wgt[4 * i + 2] = __builtin_amdgcn_s_memrealtime();
+                g_wgt[4 * i + 3] = __builtin_amdgcn_s_memtime() - c0;          // shader cycles the workgroup lived
+            }
         }
     }
 };
@@ -73,7 +76,7 @@ unsigned wgt_fetch(unsigned long long* out, unsigned cap)
     (void)hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_wgt_n), sizeof n);
     if (n > WGT_CAP) n = WGT_CAP;
     if (n > cap) n = cap;
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgt), (size_t)n * 24);
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wgt), (size_t)n * 32);
     return n;
 }
 #else

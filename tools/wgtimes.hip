@@ -4,7 +4,7 @@
 // chain and tile kernels stamps s_memrealtime (100 MHz) at its start and end (kernels.hip, WgTimer).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DCUGP_WGTIMES -w -x hip tools/wgtimes.hip cugp_amd/csrc/cugp_capi.cpp \
 //         cugp_amd/csrc/bcm.cpp cugp_amd/csrc/minimize.cpp -o tools/bin/wgtimes          (kernels.hip is included here)
-//   tools/bin/wgtimes [n=8192] [detail=0]
+//   tools/bin/wgtimes [n=8192] [detail=0] [key=value ...]     (tuning keys of kernels.h, e.g. 16=224)
 #pragma clang diagnostic ignored "-Wunused-result"
 #pragma clang diagnostic ignored "-Wunused-value"
 #include "../cugp_amd/csrc/kernels.hip"
@@ -20,7 +20,7 @@
 
 using namespace cugp;
 
-struct Rec { int kind, param; double t0, t1; };   // us
+struct Rec { int kind, param; double t0, t1, cyc; };   // us, shader cycles
 
 static double med(std::vector<double> v)
 {
@@ -86,6 +86,10 @@ int main(int argc, char** argv)
     setvbuf(stdout, NULL, _IONBF, 0);
     const int n = argc > 1 ? atoi(argv[1]) : 8192, d = 10;
     const bool detail = argc > 2 && atoi(argv[2]) != 0;
+    for (int i = 3; i < argc; i++) {
+        int k = 0, v = 0;
+        if (sscanf(argv[i], "%d=%d", &k, &v) == 2) { cugp_set_tuning(k, v); printf("tuning %d = %d\n", k, v); }
+    }
     std::mt19937_64 rng(15618);
     std::uniform_real_distribution<double> U(-10.0, 10.0);
     std::normal_distribution<double> G(0.0, 0.1);
@@ -97,7 +101,7 @@ int main(int argc, char** argv)
     cugp_gp* g = nullptr;
     if (cugp_create(n, d, 0, &g)) { printf("create: %s\n", cugp_last_error()); return 1; }
     cugp_set_data(g, X.data(), y.data());
-    std::vector<unsigned long long> raw(3u * WGT_CAP);
+    std::vector<unsigned long long> raw(4u * WGT_CAP);
     for (int overlap = 1; overlap >= 0; overlap--) {
         cugp_set_overlap(g, overlap);
         double ll, gr[3];
@@ -111,19 +115,27 @@ int main(int argc, char** argv)
         const unsigned cnt = wgt_fetch(raw.data(), WGT_CAP);
         std::vector<Rec> r(cnt);
         for (unsigned i = 0; i < cnt; i++)
-            r[i] = Rec{(int)(raw[3 * i] & 255), (int)(raw[3 * i] >> 8), raw[3 * i + 1] * 0.01, raw[3 * i + 2] * 0.01};
+            r[i] = Rec{(int)(raw[4 * i] & 255), (int)(raw[4 * i] >> 8), raw[4 * i + 1] * 0.01, raw[4 * i + 2] * 0.01, (double)raw[4 * i + 3]};
         printf("ll %.10g\n", ll);
         analyse(r, (n + 127) / 128, detail, overlap ? "overlap ON (inverse blocks beside the factorisation)" : "overlap OFF");
         // tile kernels: how long ONE workgroup takes in each regime
         const char* names[] = {"trsm", "diag-update", "potf2", "step tile", "border", "lauum", "level", "trtri_diag", "wide"};
         for (int k = 3; k <= 8; k++) {
-            std::vector<double> v;
+            std::vector<double> v, ghz;
             for (const Rec& x : r)
-                if (x.kind == k) v.push_back(x.t1 - x.t0);
+                if (x.kind == k) {
+                    v.push_back(x.t1 - x.t0);
+                    if (x.t1 - x.t0 >= 20.0) ghz.push_back(x.cyc / (x.t1 - x.t0) * 1e-3);      // s_memtime cycles / s_memrealtime us
+                }
             if (!v.empty()) {
                 std::sort(v.begin(), v.end());
-                printf("   %-11s %6zu workgroups: duration p10 %.1f  median %.1f  p90 %.1f  max %.1f us\n", names[k], v.size(), v[v.size() / 10],
+                printf("   %-11s %6zu workgroups: duration p10 %.1f  median %.1f  p90 %.1f  max %.1f us", names[k], v.size(), v[v.size() / 10],
                        v[v.size() / 2], v[v.size() * 9 / 10], v.back());
+                if (!ghz.empty()) {
+                    std::sort(ghz.begin(), ghz.end());
+                    printf("   shader clock while they ran: p10 %.2f  median %.2f  p90 %.2f GHz", ghz[ghz.size() / 10], ghz[ghz.size() / 2], ghz[ghz.size() * 9 / 10]);
+                }
+                printf("\n");
             }
         }
     }
