@@ -1,18 +1,20 @@
 #!/bin/bash
-# Regenerate everything under profiles/ for one round on the GPU box:  tools/make_profiles.sh r03
+# Regenerate everything under profiles/ for one round on the GPU box:  tools/make_profiles.sh r04
 # Outputs land in gpurun_out/profiles_<tag>/ (copy the ones to keep into profiles/).
-tag=${1:-r03}
+tag=${1:-r04}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/profiles_$tag
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 set -x
 python3 $R/bench.py > $O/${tag}_bench_line.json 2> $O/bench.err || exit 1
-for ov in 1 0; do
-  name=$([ $ov = 1 ] && echo bench || echo bench_overlap0)
-  rm -rf /tmp/prof_$name
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -- python3 $R/bench.py --overlap $ov --cpu-sample 0 --sub-steps 0 > $O/${tag}_${name}_line_under_rocprof.json 2> $O/$name.err || exit 1
-  cp $(find /tmp/prof_$name -name '*kernel_stats.csv' | head -1) $O/${tag}_${name}_n8192_kernel_stats.csv
+# one rocprofv3 --kernel-trace --stats run PER PASS of bench.py (timed = the default path `value` is measured on,
+# profiled = the same schedule with HIP events around the MFMA launches (what roofline* is computed from),
+# isolated = overlap off): a kernel's AverageNs in the CSV of a pass is then that pass's figure, nothing mixed
+for pass in timed profiled isolated; do
+  rm -rf /tmp/prof_$pass
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$pass -- python3 $R/bench.py --passes $pass --cpu-sample 0 --sub-steps 0 > $O/${tag}_bench_${pass}_line_under_rocprof.json 2> $O/bench_$pass.err || exit 1
+  cp $(find /tmp/prof_$pass -name '*kernel_stats.csv' | head -1) $O/${tag}_bench_${pass}_n8192_kernel_stats.csv
 done
 python3 $R/bench.py --rows 1500 --experts-total 16 --cpu-sample 0 > $O/${tag}_bench_bcm16_line.json 2>> $O/bench.err
 python3 $R/bench.py --rows 6000 --experts-total 4 --cpu-sample 0 --steps 10 > $O/${tag}_bench_bcm4_line.json 2>> $O/bench.err
@@ -36,9 +38,16 @@ done
 for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_LDS_BANK_CONFLICT" "FETCH_SIZE" "WRITE_SIZE"; do
   t=$(echo $pass | cut -d' ' -f1)
   rm -rf $R/gpurun_out/pmc_$t
-  rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$t -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 --sub-steps 0 > $R/gpurun_out/pmc_$t.log 2>&1 || echo "pass $t failed"
+  rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$t -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 --sub-steps 0 --passes timed > $R/gpurun_out/pmc_$t.log 2>&1 || echo "pass $t failed"
 done
 cd $R && python3 tools/pmc_summary.py $R/gpurun_out $tag && cp profiles/${tag}_pmc_summary.json $O/
+# HBM-side bytes of a whole evaluation (the run above holds 3 + 1 evaluations: warm-up, 2 steps, 1 in front of predict)
+python3 tools/pmc_total.py $R/gpurun_out 4 > $O/${tag}_pmc_total_traffic.txt 2>&1
+# per-workgroup start / end / shader-clock stamps of the chain and tile kernels (diagnostic build, see tools/wgtimes.hip)
+[ -x $R/tools/bin/wgtimes ] && $R/tools/bin/wgtimes 8192 1 > $O/${tag}_wgtimes_n8192.txt 2>&1
+[ -x $R/tools/bin/wgtimes ] && $R/tools/bin/wgtimes 1500 1 > $O/${tag}_wgtimes_n1500.txt 2>&1
+# board power and clocks while the metric workload loops (the evaluation is clock-limited: DESIGN section 8)
+( python3 $R/bench.py --passes timed --steps 400 --cpu-sample 0 --sub-steps 0 > /dev/null 2>&1 & BP=$!; sleep 4; for i in 1 2 3 4 5; do rocm-smi --showpower --showclocks 2>/dev/null | grep -i "power\|sclk\|mclk"; sleep 0.5; done; wait $BP ) > $O/${tag}_power_clocks_under_load.txt 2>&1
 # the factorisation's chain kernels alone, with in-kernel cycle stamps (built in the build container: see the sources' headers)
 [ -x $R/tools/bin/chain_bench ] && $R/tools/bin/chain_bench > $O/${tag}_chain_bench.txt 2>&1
 [ -x $R/tools/bin/panel_bench ] && $R/tools/bin/panel_bench >> $O/${tag}_chain_bench.txt 2>&1

@@ -14,10 +14,11 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out")
-tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r04"
 CLOCK_HZ, SIMDS = 2.4e9, 256 * 4
 KERNELS = ("k_syrk_step", "k_syrk_wide", "k_lauum<4>", "k_lauum<2>", "k_trtri_level<4>", "k_trtri_level<2>",
-           "k_trtri_border<4>", "k_trtri_border<2>", "k_trtri_diag", "k_build", "k_trace", "k_potf2", "k_trsm_inv64")
+           "k_trtri_border<4>", "k_trtri_border<2>", "k_trtri_diag", "k_trtri_block", "k_build", "k_trace", "k_potf2",
+           "k_trsm_inv64")
 
 
 def load(t):
