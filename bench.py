@@ -18,7 +18,7 @@ The run is made of passes (--passes, default all three, in this order):
   profiled   the same K evaluations with HIP events around the launches of every MFMA kernel on the stream each runs
              on (cugp_set_profiling 2): the `roofline*` records -- same schedule, the inverse blocks beside the
              factorisation, so a launch shares the CUs with kernels on the other streams
-  isolated   16 evaluations with the overlap off (every kernel has the chip to itself): `isolated_*`, cholesky_gflops
+  isolated   8 evaluations with the overlap off (every kernel has the chip to itself): `isolated_*`, cholesky_gflops
 tools/make_profiles.sh runs rocprofv3 --kernel-trace --stats once per pass (--passes timed | profiled | isolated), so
 the average duration of a kernel in the CSV named in roofline.dominant_by reproduces roofline.achieved.
 
@@ -54,8 +54,8 @@ MFMA_F64_PEAK_TFLOPS = 78.6                          # MI355X dense fp64 matrix 
 HBM_PEAK_GBS = 8000.0                                # MI355X HBM3E (MI355X_MICROARCH.md)
 ROUND = "r04"
 PMC_SUMMARY = "profiles/%s_pmc_summary.json" % ROUND        # rocprofv3 --pmc passes of this command (tools/pmc.sh)
-# kernels timed by the library at profiling level 2 (cugp_get_kernel_stats_kind): name as rocprofv3 prints it, what it
-# is, and one launch in how many is timed
+# kernels timed by the library (cugp_get_kernel_stats_kind): name as rocprofv3 prints it, what it is, and one launch in
+# how many is timed at profiling level 2 (the isolated pass; the profiled pass runs level 3: every launch)
 KINDS = {0: ("k_syrk_step", "Cholesky near-window trailing update + next diagonal block, K=128 per launch", 16),
          1: ("k_syrk_wide", "Cholesky far trailing update, K=128*panel per launch", 1),
          2: ("k_trtri_border<4>", "bordering steps of L^-1, 128x128 output tiles", 4),
@@ -224,7 +224,7 @@ def main():
     ph = dict(nanph)
     dt_prof = None
     if timed_launches:
-        first.set_profiling(2)
+        first.set_profiling(3)                        # HIP events around EVERY launch of the MFMA kernels
         step(0)                                       # event pools, first profiled enqueue
         for kd in KINDS:
             first.kernel_stats(reset=True, kind=kd)
@@ -237,20 +237,24 @@ def main():
 
     # ---- pass 3, isolated: the same kernels with the chip to themselves.  In the other passes the inverse blocks
     # run beside the factorisation on other streams, so a launch shares the CUs and its duration is not a statement
-    # about the kernel alone; sixteen more evaluations with the overlap off give that number.
+    # about the kernel alone; eight more evaluations with the overlap off give that number.
     iso = iso_ph = None
     if rank == 0 and can_profile and args.overlap and "isolated" in passes:
-        first.set_profiling(2)
         first.set_overlap(False)
+        first.set_profiling(1)                    # phase events only: the factorisation alone -> cholesky_gflops
+        for i in range(4):                        # (events around every launch would add ~5 us to each of its 126)
+            first.set_loghyperparam(HP0 + 1e-3 * ((i % 7) - 3))
+            first.loglik_grad()
+        iso_ph = first.phase_ms()
+        first.set_profiling(3)                    # ... and every MFMA launch with the chip to itself
         first.set_loghyperparam(HP0)
         first.loglik_grad()
         for kd in KINDS:
             first.kernel_stats(reset=True, kind=kd)
-        for i in range(16):                       # level-2 profiling times every 16th step launch, rotating
+        for i in range(8):
             first.set_loghyperparam(HP0 + 1e-3 * ((i % 7) - 3))
             first.loglik_grad()
         iso = {kd: first.kernel_stats(kind=kd) for kd in KINDS}
-        iso_ph = first.phase_ms()
         first.set_overlap(True)
     if first is not None and can_profile:
         first.set_profiling(0)
@@ -360,10 +364,10 @@ def main():
                  "traffic": pmc.get(name, {}).get("hbm_bytes_per_launch"),
                  "traffic_source": PMC_SUMMARY if name in pmc else None,
                  "mfma_busy_frac_pmc": pmc.get(name, {}).get("mfma_busy_frac"),
-                 "launches_timed": int(st["launches"]), "timed_one_launch_in": every,
+                 "launches_timed": int(st["launches"]), "timed_one_launch_in": 1,
                  "avg_launch_us": 1e3 * st["sum_ms"] / st["launches"],
                  "algorithmic_flop_per_launch": st["flop"] / st["launches"],
-                 "est_ms_per_eval": every * st["sum_ms"] / args.steps}
+                 "est_ms_per_eval": st["sum_ms"] / args.steps}
             if iso_st and iso_st["launches"] > 0:
                 ia = iso_st["flop"] / (iso_st["sum_ms"] * 1e-3) / 1e12
                 r.update({"isolated_achieved": ia, "isolated_frac": ia / MFMA_F64_PEAK_TFLOPS,
@@ -391,15 +395,15 @@ def main():
             ks, kw = kst[0], kst[1]
             if ks["launches"] > 0 and kw["launches"] > 0:
                 # the two kernels of the factorisation's trailing update together: their flop over the sum of their
-                # durations (every wide launch is timed, one step launch in 16: scale the step sample up)
-                fl = kw["flop"] + 16.0 * ks["flop"]
-                ms = kw["sum_ms"] + 16.0 * ks["sum_ms"]
+                # durations (profiled pass: every launch of both is timed)
+                fl = kw["flop"] + ks["flop"]
+                ms = kw["sum_ms"] + ks["sum_ms"]
                 tu = {"what": "k_syrk_wide + k_syrk_step together (N^3/3 flop of the factorisation)",
                       "achieved": fl / (ms * 1e-3) / 1e12, "unit": "TFLOP/s", "peak": MFMA_F64_PEAK_TFLOPS,
                       "wide_share_of_flop": kw["flop"] / fl}
                 tu["frac"] = tu["achieved"] / MFMA_F64_PEAK_TFLOPS
                 if iso and iso[0]["launches"] > 0 and iso[1]["launches"] > 0:
-                    ia = (iso[1]["flop"] + 16.0 * iso[0]["flop"]) / ((iso[1]["sum_ms"] + 16.0 * iso[0]["sum_ms"]) * 1e-3) / 1e12
+                    ia = (iso[1]["flop"] + iso[0]["flop"]) / ((iso[1]["sum_ms"] + iso[0]["sum_ms"]) * 1e-3) / 1e12
                     tu["isolated_achieved"], tu["isolated_frac"] = ia, ia / MFMA_F64_PEAK_TFLOPS
                 out["roofline_trailing_update"] = tu
         if timed_launches and ph["kbuild"] == ph["kbuild"]:

@@ -48,7 +48,8 @@ int fail(int code, const char* what, hipError_t e = hipSuccess)
 constexpr int NPHASE = 6;
 constexpr int MAX_KEV = 4096;   // per-launch event pairs kept between resets
 constexpr int GRAPH_MAX_TILES = 24;   // evaluations up to 3072 rows are replayed as captured graphs
-constexpr int PROF_STRIDE = 16; // profiling level 2 times every 16th step launch, rotating (an event pair costs ~5 us of device time)
+constexpr int PROF_STRIDE = 16; // profiling level 2 times every 16th step launch, rotating (an event pair costs ~5 us of device time);
+                                // level 3 times EVERY launch of the MFMA kernels (bench.py's profiled pass: averages comparable with rocprofv3's)
 // kinds of timed launches (cugp_get_kernel_stats_kind): the kernels as rocprofv3 names them
 enum { KIND_STEP = 0, KIND_WIDE = 1, KIND_BORDER4 = 2, KIND_BORDER2 = 3, KIND_LAUUM4 = 4, KIND_LAUUM2 = 5,
        KIND_LEVEL4 = 6, KIND_LEVEL2 = 7, KIND_BLOCK = 8, KIND_COUNT = 9 };
@@ -201,6 +202,9 @@ struct TimedLaunch {
     }
 };
 
+// is this launch one of the timed ones?  level 2: one in `every`, rotating with `phase`; level 3: all
+bool sampled(const cugp_gp* g, int phase, int every) { return g->prof >= 3 || (g->prof == 2 && phase % every == 0); }
+
 // algorithmic flop of the inverse's tile products (multiply + add; a k tile that is triangular counts half).
 // border step 1, one chunk: Wt(tj < c1, ti in [ra, ra+rw)) (+)= sum_{k in [max(tj,c0), c1)} U[tj][k] L[ti][k]
 double border1_flop(int rw, int c0, int c1)
@@ -245,10 +249,9 @@ double level_flop(int nt, int s, int step)
 int enqueue_block_own_inverse(cugp_gp* g, int a, int wb, hipStream_t o)
 {
     const int ld = g->npad;
-    const bool timed = g->prof >= 2;
     if (wb <= TRTRI_BLOCK_MAX_TILES) {
         unsigned* base = g->grp ? g->grp->tickets : g->dtickets;
-        TimedLaunch tl(g, o, timed && ((a / (wb > 0 ? wb : 1)) + (int)g->eval_seq) % 4 == 0);
+        TimedLaunch tl(g, o, sampled(g, (a / (wb > 0 ? wb : 1)) + (int)g->eval_seq, 4));
         launch_trtri_block(g->dA, g->d64, g->dT, g->dU, ld, a, wb, base + g->nt + a, g->dlogdet, g->nt + a, o, B(g));
         double fl = 0;
         for (int s = 1; s < wb; s *= 2) fl += level_flop(wb, s, 1) + level_flop(wb, s, 2);
@@ -259,7 +262,7 @@ int enqueue_block_own_inverse(cugp_gp* g, int a, int wb, hipStream_t o)
     launch_trtri_diag(g->dA, ld, a, wb, g->d64, g->dT, g->dU, o, B(g));
     for (int s = 1; s < wb; s *= 2)
         for (int step = 1; step <= 2; step++) {
-            TimedLaunch tl(g, o, timed && (a + s + step + (int)g->eval_seq) % 16 == 0);  // small launches: one in sixteen
+            TimedLaunch tl(g, o, sampled(g, a + s + step + (int)g->eval_seq, 16));  // small launches: one in sixteen
             const int wm = launch_trtri_level(g->dA, g->dT, g->dU, ld, wb, s, step, o, B(g), off);
             if (wm) tl.done(wm == 4 ? KIND_LEVEL4 : KIND_LEVEL2, level_flop(wb, s, step));
         }
@@ -277,7 +280,6 @@ int enqueue_inverse_block(cugp_gp* g, int a, int b, bool kinv, hipStream_t x, hi
 {
     const int ld = g->npad, wb = b - a;
     hipStream_t o = xs ? xs : x;
-    const bool timed = g->prof >= 2;
     int rc0;
     if ((rc0 = enqueue_block_own_inverse(g, a, wb, o))) return rc0;
     if (xs) {
@@ -285,7 +287,7 @@ int enqueue_inverse_block(cugp_gp* g, int a, int b, bool kinv, hipStream_t x, hi
         HIPCHK(hipStreamWaitEvent(x, own_done, 0));
     }
     // rows [a, b): their Wt was accumulated chunk by chunk while the earlier blocks became final
-    const bool timed2 = timed && ((a / (wb > 0 ? wb : 1)) + (int)g->eval_seq) % 4 == 0;   // large launches: every fourth block
+    const bool timed2 = sampled(g, (a / (wb > 0 ? wb : 1)) + (int)g->eval_seq, 4);   // large launches: every fourth block
     if (a > 0) {
         TimedLaunch tl(g, x, timed2);
         const int wm = launch_trtri_border2(g->dA, g->dT, g->dU, ld, a, wb, x, B(g));
@@ -347,10 +349,9 @@ int enqueue_last_block(cugp_gp* g, int a, int idx)
 {
     const int nt = g->nt, ld = g->npad, wb = nt - a;
     hipStream_t m = g->stream;
-    const bool timed = g->prof >= 2;
     int rc0;
     if ((rc0 = enqueue_block_own_inverse(g, a, wb, m))) return rc0;
-    const bool timed2 = timed && ((a / (wb > 0 ? wb : 1)) + (int)g->eval_seq) % 4 == 0;
+    const bool timed2 = sampled(g, (a / (wb > 0 ? wb : 1)) + (int)g->eval_seq, 4);
     HIPCHK(hipStreamWaitEvent(m, g->bev.back(), 0));
     {
         TimedLaunch tl(g, m, timed2);
@@ -537,7 +538,7 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false, const unsign
         }
         // level 2 times a rotating eighth of the step launches (every step is sampled once in 8 evaluations):
         // an event pair around every launch costs several percent of the evaluation
-        TimedLaunch tl(g, m, g->prof >= 2 && (kb + g->eval_seq) % PROF_STRIDE == 0);
+        TimedLaunch tl(g, m, sampled(g, kb + (int)g->eval_seq, PROF_STRIDE));
         // (look-ahead form: plain stores -- the panel solve that follows reads the column at once, and reading
         //  freshly non-temporally stored tiles took it 50 us instead of 16)
         launch_syrk_step(g->dA, ld, kb, nt, g->d16, g->d64, g->dlogdet, g->dtickets, m, B(g), sp.wcol,

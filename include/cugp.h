@@ -115,14 +115,16 @@ int cugp_potrs_vec(int n, const double *K, const double *y, double *x, int devic
  * phases: 0 kernel build, 1 Cholesky, 2 triangular inverse, 3 K^-1 product, 4 vectors+traces+finalize, 5 total;
  * cugp_get_kernel_stats: HIP-event time of every launch of the Cholesky trailing update (MFMA SYRK) in the
  * evaluations since the last reset: sum of durations (ms), launches, algorithmic flop */
-int cugp_set_profiling(cugp_gp *gp, int level /* 0 off, 1 phases, 2 phases + per-launch SYRK events */);
+int cugp_set_profiling(cugp_gp *gp, int level /* 0 off, 1 phases, 2 phases + HIP events around a rotating sample of the
+                                                 MFMA kernels' launches, 3 phases + events around every such launch */);
 int cugp_get_phase_ms(cugp_gp *gp, double ms[6]);
 int cugp_get_kernel_stats(cugp_gp *gp, double *sum_ms, long long *launches, double *flop, int reset);
 /* the same per kernel, as rocprofv3 names them: kind 0 = k_syrk_step (near-window update + next diagonal block,
  * K = 128; timed one launch in 16, rotating), 1 = k_syrk_wide (the far trailing matrix once per panel, K = 128 * panel
  * width), 2 / 3 = k_trtri_border<4> / <2> (bordering steps of L^-1) and 4 / 5 = k_lauum<4> / <2> (shares of K^-1):
  * timed for every fourth block of inverse rows, 6 / 7 = k_trtri_level<4> / <2> (doubling inside a block of rows; timed
- * one launch in 16).  flop = algorithmic
+ * one launch in 16), 8 = k_trtri_block (a hand-over block's own inverse in one launch; every fourth block).  The
+ * sampling rates are those of level 2; level 3 times every launch.  flop = algorithmic
  * (entries on or below the diagonal, a triangular k tile counted half), multiply + add */
 int cugp_get_kernel_stats_kind(cugp_gp *gp, int kind, double *sum_ms, long long *launches, double *flop, int reset);
 void *cugp_get_stream(cugp_gp *gp);          /* hipStream_t of the handle */
