@@ -11,6 +11,14 @@
 #include "../../cugp_amd/host/bcm_solve.h"
 #include "../../cugp_amd/host/gp_api.h"
 
+// the reference's driver takes its BCM BY VALUE (distributed_gp/distributed_ver1.cpp:13,285): copies of the drop-in
+// class share one device-side model
+static double ll_by_value(BCM pobj, double *hp3)
+{
+    pobj.set_BCM_log_hyperparam(hp3);                    // seen by the caller's object too, as with the reference's shallow copy
+    return pobj.get_BCM_loglikelihood();
+}
+
 static void pv(const char *k, const double *v, int n, bool last = false)
 {
     printf("\"%s\": [", k);
@@ -82,6 +90,19 @@ int main(int argc, char **argv)
         poe.compute_BCM_test_means_and_var(X + ntrain, tm.data(), tv.data(), ntest);
         pv("bcm_pred_mean", tm.data(), ntest);
         pv("bcm_pred_var", tv.data(), ntest);
+        {
+            double hp2[] = {1.25, 1.0, 0.5};
+            const double llv = ll_by_value(poe, hp2);     // copy made and destroyed: the model must survive it
+            double seen[3];
+            poe.get_loghyperparam(seen);
+            pv("bcm_byvalue_hp_seen", seen, 3);
+            printf("\"bcm_byvalue_ll\": %.17g,\n\"bcm_after_copy_ll\": %.17g,\n", llv, poe.get_BCM_loglikelihood());
+            BCM second = poe;                             // copy construction + assignment
+            BCM third(X, y, 64, dim, 2);
+            third = second;
+            printf("\"bcm_assigned_ll\": %.17g,\n", third.get_BCM_loglikelihood());
+            poe.set_BCM_log_hyperparam(inithypervalues);
+        }
         cugp_cg_solve(poe);
         double hp[3];
         poe.get_loghyperparam(hp);
@@ -96,6 +117,13 @@ int main(int argc, char **argv)
         double g[3];
         compute_gradient_log_hyperparams(g);
         pv("api_grad", g, 3);
+        // the multi-node drivers' path (cuda_scalingdist/main.cpp:99-121, cg_solver.cpp:42-70): a chunk read into one of
+        // the two host buffers setup() allocated, X_host / labels_host pointed at it, copied to the device
+        read_trainingdata_into_dram(argv[1], argv[2], X_host_buffers[1], labels_host_buffers[1]);
+        X_host = X_host_buffers[1];
+        labels_host = labels_host_buffers[1];
+        copy_training_data_to_GPU(X_host, labels_host);
+        printf("\"api_ll_from_buffer\": %.17g,\n", compute_log_likelihood());
         cg_solve(argv[0]);
         pv("api_cg_final_hp", get_loghyperparam(), 3, true);
         printf("}\n");

@@ -69,6 +69,14 @@ def test_cpp_dropin_driver(tmp_path, si128, golden_si128, oracle):
     assert np.allclose(r["bcm_pred_var"], bv, rtol=1e-8, atol=1e-8)
     bf, _ = b.cg_solve()
     assert np.allclose(r["bcm_cg_final_hp"], bf, atol=5e-5)
+    # BCM passed by value (distributed_ver1.cpp:13,285): the copy drives the same device model, hyper-parameters set
+    # through it are the object's, and the model survives the copy's destruction; assignment shares it too
+    b2 = o.bcm(Xtr, ytr, 4, [1.25, 1.0, 0.5])
+    assert r["bcm_byvalue_hp_seen"] == [1.25, 1.0, 0.5]
+    assert abs(r["bcm_byvalue_ll"] - b2.loglik()[0]) <= 1e-8 * abs(r["bcm_byvalue_ll"])
+    assert r["bcm_after_copy_ll"] == r["bcm_byvalue_ll"] == r["bcm_assigned_ll"]
+    # surface B through the double buffers the reference's background reader fills
+    assert r["api_ll_from_buffer"] == r["api_ll"]
 
 
 def test_cpp_rccl_driver_one_rank(tmp_path):
