@@ -296,6 +296,25 @@ def job(r, name):
         m, v = b.predict(Xt)
         out = {"K": 4, "rows": [0, 24000], "hp": HP_DENSE, "Xt": Xt.tolist(), "yt": yt.tolist(),
                "pred_mean": m.tolist(), "pred_var": v.tolist(), "nlpp": b.nlpp(yt, m, v)}
+    elif name in ("cg_sine2048", "rprop_sine1024"):
+        # round 4: optimiser trajectories at larger sizes (covkernel.cpp:337-402, 405-647)
+        d = np.load(os.path.join(HERE, "data_sine_4160.npz"))
+        n = 2048 if name == "cg_sine2048" else 1024
+        X, y = d["X"][:n], d["y"][:n]
+        log = os.path.join(tempfile.mkdtemp(), "opt.log")
+        final = (r.cg_solve if name.startswith("cg") else r.rprop_solve)(X, y, HP_DENSE, log)
+        out = {"rows": "sine_%d" % n, "n": n, "hp0": HP_DENSE, "final_hp": final.tolist(),
+               "final_ll": r.loglik(X, y, final), "please_see": parse_please_see(log)}
+    elif name == "bcm16_cg_8000":
+        # round 4: cg_solve(BCM) (distributed_ver1.cpp:13-232) on 16 experts x 500 rows (rows 0..7999 of si24000)
+        X, y = _rows("si24000")
+        X, y = X[:8000], y[:8000]
+        b = r.bcm(X, y, 16, HP_DENSE)
+        log = os.path.join(tempfile.mkdtemp(), "bcmcg.log")
+        final = b.cg_solve(log)
+        b2 = r.bcm(X, y, 16, final.tolist())
+        out = {"K": 16, "rows": [0, 8000], "hp0": HP_DENSE, "final_hp": final.tolist(), "final_ll": b2.loglik(),
+               "please_see": parse_please_see(log)}
     elif re.match(r"(tail|ill)(\d+)_(ll|grad)$", name):
         # round 3: the ill-conditioned regime.  "tail" = REF's end point on sine rows; "ill" = the dense
         # length scale of HP_DENSE with the tail's amplitude and noise (cond(K) ~ n*sf2/sn2)
@@ -335,7 +354,8 @@ JOBS = (["s10000_grad", "d8192_grad", "s10000_ll"] + ["si6000_%d_grad" % k for k
 JOBS_R3 = ["tail4096_grad", "ill4096_grad", "si24000_bcm16_tail", "tail4096_ll", "ill4096_ll", "cg_sine1024",
            "tail2048_grad", "ill2048_grad", "tail2048_ll", "ill2048_ll",
            "d8192_grad_ill", "d8192_ll_ill", "si24000_bcm16_ill"]           # round 3 (written into golden_r2/ too)
-JOBS_R4 = ["si6000_poe", "pred8192_dense", "pred8192_ill", "pred4096"]      # round 4: prediction at size
+JOBS_R4 = ["si6000_poe", "pred8192_dense", "pred8192_ill", "pred4096",     # round 4: prediction at size
+           "cg_sine2048", "rprop_sine1024", "bcm16_cg_8000"]                 # ... and optimiser trajectories
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -263,3 +263,64 @@ def test_config4_si6000_poe_prediction_golden(gp_mod, si24000):
     nlpp = b.get_BCM_negative_log_predprob(np.array(c["yt"]), m, v)
     assert abs(nlpp - c["nlpp"]) <= 1e-8 * max(1.0, abs(c["nlpp"]))
     b.close()
+
+
+# ------------------------------------------------------------------ round 4: optimiser trajectories at larger sizes
+def _probes_match(tr, c, min_moving):
+    """The GPU run's probe points against the reference's PLEASE-SEE trace: one for one while the objective still
+    moves (|f - f_final| > 1e-9 |f_final|); where the objective is flat to rounding the direction is noise in any
+    correct implementation (test_cg_trajectory_sine_1024 explains)."""
+    probes = np.array([p[1:] for p in c["please_see"] if p[0] in (1, 2)])
+    assert tr.shape[0] == probes.shape[0] + 1, (tr.shape, probes.shape)
+    err = np.abs(tr[1:, :3] - probes) / np.maximum(1.0, np.abs(probes))
+    moving = np.abs(tr[1:, 3] + c["final_ll"]) > 1e-9 * abs(c["final_ll"])
+    assert moving.sum() >= min_moving and np.all(err[moving] <= 5e-5), (int(moving.sum()), float(np.max(err[moving])))
+    return err, moving
+
+
+def test_cg_trajectory_sine_2048(gp_mod, sine4160):
+    """Covsum::cg_solve (covkernel.cpp:405-647) on sine rows 0..2047 from the dense starting point: the reference's
+    100-evaluation run (about an hour of its time) probe for probe."""
+    X, y = sine4160
+    c = job("cg_sine2048")
+    g = gp_mod.Covsum(2048, 10)
+    g.set_loghyperparam(c["hp0"])
+    tr = g.cg_solve(X[:2048], y[:2048])
+    err, moving = _probes_match(tr, c, 20)
+    print("cg_sine2048: %d probes, %d while the objective moves, max rel. deviation there %.2e" % (err.shape[0], moving.sum(), np.max(err[moving])))
+    final = g.get_loghyperparam()
+    if moving[-1]:                                                           # the run ended while still descending
+        assert np.allclose(final, c["final_hp"], atol=5e-5), (final, c["final_hp"])
+    assert abs(g.compute_loglikelihood() - c["final_ll"]) <= 1e-7 * abs(c["final_ll"])
+    g.close()
+
+
+def test_rprop_sine_1024(gp_mod, sine4160):
+    """Covsum::rprop_solve (covkernel.cpp:337-402), 100 iterations on sine rows 0..1023."""
+    X, y = sine4160
+    c = job("rprop_sine1024")
+    g = gp_mod.Covsum(1024, 10)
+    g.set_loghyperparam(c["hp0"])
+    tr = g.rprop_solve(X[:1024], y[:1024])
+    assert tr.shape[0] == 200
+    final = g.get_loghyperparam()
+    assert np.allclose(final, c["final_hp"], atol=5e-5), (final, c["final_hp"])
+    assert abs(g.compute_loglikelihood() - c["final_ll"]) <= 1e-7 * max(1.0, abs(c["final_ll"]))
+    g.close()
+
+
+def test_bcm16_cg_8000(gp_mod, si24000):
+    """cg_solve(BCM) (distributed_gp/distributed_ver1.cpp:13-232): 16 experts x 500 rows (rows 0..7999 of si24000), the
+    reference's whole 100-evaluation run; the GPU side runs the library's host loop on the grouped experts."""
+    X, y = si24000
+    c = job("bcm16_cg_8000")
+    b = gp_mod.BCM.split(X[:8000], y[:8000], 16)
+    b.set_BCM_log_hyperparam(c["hp0"])
+    tr = b.cg_solve()
+    err, moving = _probes_match(tr, c, 20)
+    print("bcm16_cg_8000: %d probes, %d while the objective moves, max rel. deviation there %.2e" % (err.shape[0], moving.sum(), np.max(err[moving])))
+    if moving[-1]:
+        assert np.allclose(b.get_loghyperparam(), c["final_hp"], atol=5e-5)
+    ll, _, _ = b.loglik_grad()
+    assert abs(ll - c["final_ll"]) <= 1e-7 * abs(c["final_ll"])
+    b.close()
