@@ -12,6 +12,9 @@ Outputs : expected values computed by the reference's own C++ compiled where it
 Also    : the numeric trace of the reference's committed run log
           cuda_bettersinglenode_ver2/REF -> ref_log_si128.json
 
+Round 4 (prediction at size, optimiser trajectories): --job list4 names them; pred8192_* take ~2.3 h each, si6000_poe
+~3.4 h, the others minutes to an hour.
+
 Round 2 (configs 3-5 and a dense metric-size case; CPU-hours, so one job per
 process, see run_jobs.sh):
     python tests/golden/make_golden.py --job data        # data_si24000.npz, data_siproper_10000.npz
@@ -368,6 +371,9 @@ if __name__ == "__main__":
         raise SystemExit(0)
     if a.job == "list3":
         print("\n".join(JOBS_R3))
+        raise SystemExit(0)
+    if a.job == "list4":
+        print("\n".join(JOBS_R4))
         raise SystemExit(0)
     if a.job == "data":
         make_data()
