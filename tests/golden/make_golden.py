@@ -318,6 +318,23 @@ def job(r, name):
         b2 = r.bcm(X, y, 16, final.tolist())
         out = {"K": 16, "rows": [0, 8000], "hp0": HP_DENSE, "final_hp": final.tolist(), "final_ll": b2.loglik(),
                "please_see": parse_please_see(log)}
+    elif name == "bcm5_6007":
+        # round 4: an uneven in-memory BCM at a middle size: 6007 rows in 5 experts -> 1201 x 4 + 1203 (BCM.cpp:85-110:
+        # the remainder goes to the last expert), likelihood, gradient, product-of-experts prediction, NLPP
+        X, y = _rows("si24000")
+        X, y = X[9000:9000 + 6007], y[9000:9000 + 6007]
+        Xt = np.vstack([X[::250] * 0.9 + 0.05, X[100::500] * 0.8 - 0.1])
+        yt = np.concatenate([y[::250], y[100::500]])
+        out = {"K": 5, "rows": [9000, 15007], "cases": []}
+        for hp in (HP_DENSE, HP_TWO):
+            b = r.bcm(X, y, 5, hp)
+            log = os.path.join(tempfile.mkdtemp(), "ll.log")
+            ll = b.loglik(log)
+            per = [float(m.group(1)) for m in re.finditer(r"LL of Expert \d+: ([-\d.]+)", open(log).read())]
+            g = b.grad()
+            m, v = b.predict(Xt)
+            out["cases"].append({"hp": hp, "ll": ll, "ll_per_expert_6dp": per, "grad": g.tolist(), "Xt": Xt.tolist(),
+                                 "yt": yt.tolist(), "pred_mean": m.tolist(), "pred_var": v.tolist(), "nlpp": b.nlpp(yt, m, v)})
     elif re.match(r"(tail|ill)(\d+)_(ll|grad)$", name):
         # round 3: the ill-conditioned regime.  "tail" = REF's end point on sine rows; "ill" = the dense
         # length scale of HP_DENSE with the tail's amplitude and noise (cond(K) ~ n*sf2/sn2)
@@ -358,7 +375,7 @@ JOBS_R3 = ["tail4096_grad", "ill4096_grad", "si24000_bcm16_tail", "tail4096_ll",
            "tail2048_grad", "ill2048_grad", "tail2048_ll", "ill2048_ll",
            "d8192_grad_ill", "d8192_ll_ill", "si24000_bcm16_ill"]           # round 3 (written into golden_r2/ too)
 JOBS_R4 = ["si6000_poe", "pred8192_dense", "pred8192_ill", "pred4096",     # round 4: prediction at size
-           "cg_sine2048", "rprop_sine1024", "bcm16_cg_8000"]                 # ... and optimiser trajectories
+           "cg_sine2048", "rprop_sine1024", "bcm16_cg_8000", "bcm5_6007"]                 # ... and optimiser trajectories
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

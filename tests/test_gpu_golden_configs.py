@@ -334,3 +334,25 @@ def test_bcm16_cg_8000(gp_mod, si24000):
     ll, _, _ = b.loglik_grad()
     assert abs(ll - c["final_ll"]) <= 1e-7 * abs(c["final_ll"])
     b.close()
+
+
+@pytest.mark.parametrize("case", [0, 1])
+def test_uneven_bcm5_6007_golden(gp_mod, si24000, case):
+    """An uneven BCM at a middle size on the reference's data: rows 9000..15006 of si24000 in 5 experts = 1201 x 4 + 1203
+    (BCM.cpp:85-110 gives the remainder to the last expert; on the GPU the five share launches at a common padded size of
+    10 tiles): likelihood, gradient, per-expert likelihoods, product-of-experts prediction and NLPP, two hyper-parameter
+    points."""
+    X, y = si24000
+    X, y = np.ascontiguousarray(X[9000:9000 + 6007]), np.ascontiguousarray(y[9000:9000 + 6007])
+    c = job("bcm5_6007")["cases"][case]
+    b = gp_mod.BCM.split(X, y, 5)
+    b.set_BCM_log_hyperparam(c["hp"])
+    ll, gr, per = b.loglik_grad()
+    assert ll_close(ll, c["ll"]), (ll, c["ll"])
+    assert grad_close(gr, c["grad"]), (gr, c["grad"])
+    assert np.allclose(per, c["ll_per_expert_6dp"], rtol=0, atol=6e-7)
+    m, v = b.compute_BCM_test_means_and_var(np.array(c["Xt"]))
+    assert pred_close(m, c["pred_mean"]) and pred_close(v, c["pred_var"])
+    nlpp = b.get_BCM_negative_log_predprob(np.array(c["yt"]), m, v)
+    assert abs(nlpp - c["nlpp"]) <= 1e-8 * max(1.0, abs(c["nlpp"]))
+    b.close()
