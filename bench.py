@@ -15,9 +15,10 @@ and the per-evaluation exchange is one all-reduce of K x 4 doubles over RCCL.
 
 The run is made of passes (--passes, default all three, in this order):
   timed      W warm-up + K evaluations on the DEFAULT path (no per-launch events, no instrumentation): `value`
-  profiled   the same K evaluations with HIP events around the launches of every MFMA kernel on the stream each runs
-             on (cugp_set_profiling 2): the `roofline*` records -- same schedule, the inverse blocks beside the
-             factorisation, so a launch shares the CUs with kernels on the other streams
+  profiled   the same K evaluations with every launch of every MFMA kernel timed by its OWN start / stop events
+             (cugp_set_profiling 4: hipExtLaunchKernelGGL, the dispatch's begin / end as rocprofv3 --kernel-trace
+             reports them, no extra packets on the streams): the `roofline*` records -- same schedule, the inverse
+             blocks beside the factorisation, so a launch shares the CUs with kernels on the other streams
   isolated   8 evaluations with the overlap off (every kernel has the chip to itself): `isolated_*`, cholesky_gflops
 tools/make_profiles.sh runs rocprofv3 --kernel-trace --stats once per pass (--passes timed | profiled | isolated), so
 the average duration of a kernel in the CSV named in roofline.dominant_by reproduces roofline.achieved.
@@ -52,7 +53,7 @@ N_METRIC, D_METRIC = 8192, 10
 HP0 = np.array([np.log(3.0), 0.0, np.log(0.1)])      # non-degenerate point: K is dense, cond ~ 1e3
 MFMA_F64_PEAK_TFLOPS = 78.6                          # MI355X dense fp64 matrix peak (spec)
 HBM_PEAK_GBS = 8000.0                                # MI355X HBM3E (MI355X_MICROARCH.md)
-ROUND = "r04"
+ROUND = "r05"
 PMC_SUMMARY = "profiles/%s_pmc_summary.json" % ROUND        # rocprofv3 --pmc passes of this command (tools/pmc.sh)
 # kernels timed by the library (cugp_get_kernel_stats_kind): name as rocprofv3 prints it, what it is, and one launch in
 # how many is timed at profiling level 2 (the isolated pass; the profiled pass runs level 3: every launch)
@@ -126,6 +127,9 @@ def main():
                     "and no extra pass is made)")
     ap.add_argument("--passes", default="timed,profiled,isolated", help="comma list of timed, profiled, isolated (see the "
                     "module docstring); the contract line needs `timed`")
+    ap.add_argument("--prof-level", type=int, default=4, help="profiling level of the profiled / isolated passes: 4 = every "
+                    "MFMA launch carries its own start / stop events (hipExtLaunchKernelGGL), 3 = an event pair recorded "
+                    "around every such launch (rounds 3-4: ~6 us of dispatch gap inside the bracket, ~5 us of device time per pair)")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
@@ -224,7 +228,7 @@ def main():
     ph = dict(nanph)
     dt_prof = None
     if timed_launches:
-        first.set_profiling(3)                        # HIP events around EVERY launch of the MFMA kernels
+        first.set_profiling(args.prof_level)          # EVERY launch of the MFMA kernels timed
         step(0)                                       # event pools, first profiled enqueue
         for kd in KINDS:
             first.kernel_stats(reset=True, kind=kd)
@@ -246,7 +250,7 @@ def main():
             first.set_loghyperparam(HP0 + 1e-3 * ((i % 7) - 3))
             first.loglik_grad()
         iso_ph = first.phase_ms()
-        first.set_profiling(3)                    # ... and every MFMA launch with the chip to itself
+        first.set_profiling(args.prof_level)      # ... and every MFMA launch with the chip to itself
         first.set_loghyperparam(HP0)
         first.loglik_grad()
         for kd in KINDS:
@@ -276,6 +280,23 @@ def main():
         predict = {"what": "predictive mean + variance of 1000 test points against the N=%d model (host arrays in, "
                            "host arrays out; factor and inverse resident)" % args.n, "ntest": 1000, "ms": pms,
                    "points_per_s": 1000.0 / (pms * 1e-3)}
+        # its MFMA kernel: W = Ks L^-T, test tile x row tile ti sums the k tiles <= ti (the diagonal k tile of the
+        # triangular L^-1 counted half): ntest_tiles * nt^2 / 2 * 2 * 128^3 flop -- HALF of the square product's
+        first.set_profiling(args.prof_level)
+        first.kernel_stats(reset=True, kind=9)
+        for _ in range(5):
+            first.compute_test_means_and_variances(None, None, Xt)
+        pst = first.kernel_stats(kind=9)
+        first.set_profiling(0)
+        if pst["launches"] > 0:
+            pach = pst["flop"] / (pst["sum_ms"] * 1e-3) / 1e12
+            predict["roofline"] = {"kernel": "k_predict_gemm (W = Ks L^-T, K = 128 (ti + 1) per output tile; fp64 MFMA 16x16x4)",
+                                   "bound": "mfma", "achieved": pach, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                   "frac": pach / MFMA_F64_PEAK_TFLOPS, "avg_launch_us": 1e3 * pst["sum_ms"] / pst["launches"],
+                                   "algorithmic_flop_per_launch": pst["flop"] / pst["launches"],
+                                   "launches_timed": int(pst["launches"]),
+                                   "note": "triangular operand: 8 test tiles x 64 row tiles x (ti + 1/2) k tiles = 6.87e10 flop "
+                                           "at N=8192, 1000 test points -- half of 2*1024*8192^2"}
 
     # BASELINE configs 5 and 4 as strong-scaling sub-runs in the same process group: the si24000 16-shard and the
     # si6000 4-chunk shapes (synthetic rows), expert k on rank k mod N (cuda_scalingdist/cg_solver.cpp:93,166), one
@@ -387,9 +408,9 @@ def main():
                                               "of the timed pass: profiles/%s_bench_timed_n8192_kernel_stats.csv, of the "
                                               "isolated pass: profiles/%s_bench_isolated_n8192_kernel_stats.csv"
                                               % (ROUND, ROUND, ROUND))
-            out["roofline"]["note"] = ("achieved/frac: profiled pass = the timed pass's schedule with HIP events around "
-                                       "the launches, where a launch shares the CUs with kernels on the other streams; "
-                                       "isolated_*: same kernel, overlap off")
+            out["roofline"]["note"] = ("achieved/frac: profiled pass = the timed pass's schedule with every launch timed by "
+                                       "its own start/stop events (level %d), where a launch shares the CUs with kernels "
+                                       "on the other streams; isolated_*: same kernel, overlap off" % args.prof_level)
             out["roofline"]["whole_evaluation_frac"] = out["eval_tflops_n3"] / MFMA_F64_PEAK_TFLOPS
             out["roofline_kernels"] = recs
             ks, kw = kst[0], kst[1]

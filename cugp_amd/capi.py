@@ -19,6 +19,7 @@ VALUE_FN = C.CFUNCTYPE(None, C.c_void_p, _dp, _dp)
 GRADIENT_FN = C.CFUNCTYPE(None, C.c_void_p, _dp, _dp)
 
 CUGP_OK = 0
+CUGP_ERR_INVALID, CUGP_ERR_NOMEM, CUGP_ERR_DEVICE, CUGP_ERR_NODEVICE = -1, -2, -3, -4
 ERR_NAMES = {-1: "CUGP_ERR_INVALID", -2: "CUGP_ERR_NOMEM", -3: "CUGP_ERR_DEVICE", -4: "CUGP_ERR_NODEVICE",
              -5: "CUGP_ERR_BUSY"}
 
@@ -92,6 +93,8 @@ SIGNATURES = {
     "cugp_test_gemm_nt": (C.c_int, [C.c_int, C.c_int, C.c_int, _dp, _dp, _dp, C.c_int]),
     "cugp_mfma_peak_tflops": (C.c_int, [C.c_int, _dp]),
     "cugp_set_tuning": (C.c_int, [C.c_int, C.c_int]),
+    "cugp_set_handle_tuning": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "cugp_get_handle_tuning": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "cugp_bench_la": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
     "cugp_bench_la_check": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp]),
     "cugp_potrf_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _ip]),

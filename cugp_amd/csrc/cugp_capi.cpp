@@ -12,11 +12,13 @@
 // T, U, Kinv are allocated on first use (gradient / prediction), A on first evaluation.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -52,7 +54,7 @@ constexpr int PROF_STRIDE = 16; // profiling level 2 times every 16th step launc
                                 // level 3 times EVERY launch of the MFMA kernels (bench.py's profiled pass: averages comparable with rocprofv3's)
 // kinds of timed launches (cugp_get_kernel_stats_kind): the kernels as rocprofv3 names them
 enum { KIND_STEP = 0, KIND_WIDE = 1, KIND_BORDER4 = 2, KIND_BORDER2 = 3, KIND_LAUUM4 = 4, KIND_LAUUM2 = 5,
-       KIND_LEVEL4 = 6, KIND_LEVEL2 = 7, KIND_BLOCK = 8, KIND_COUNT = 9 };
+       KIND_LEVEL4 = 6, KIND_LEVEL2 = 7, KIND_BLOCK = 8, KIND_PREDICT = 9, KIND_COUNT = 10 };
 
 // One hardware queue per stream up to 16 (the runtime default is 4): the experts of a BCM on one device each
 // drive their own stream, and 16 experts on 4 queues serialise (5.8 ms vs 4.6 ms per evaluation of 16 x 1500
@@ -104,7 +106,13 @@ struct cugp_gp {
     HyperScalars* dhs = nullptr;   // device copy of exp(2*theta): what the kernels of a captured evaluation read
     HyperScalars* hhs = nullptr;   // pinned staging for it (refreshed by a copy node at the head of the graph)
     hipGraphExec_t gexec[2] = {nullptr, nullptr};   // [0] log-likelihood only, [1] with gradient
-    unsigned gepoch[2] = {0, 0};   // g_cfg_epoch the graph was captured under
+    unsigned gepoch[2] = {0, 0};   // cfg_epoch the graph was captured under
+    // launch-shape tuning of THIS handle (kernels.h TUNE_*): the process defaults as of the last sync_tuning(), except the
+    // keys set for this handle alone (cugp_set_handle_tuning)
+    int tune[TUNE_COUNT] = {};
+    bool tune_own[TUNE_COUNT] = {};
+    unsigned cfg_epoch = 1;        // bumped when a launch shape of this handle changed: captured graphs carry launch shapes
+    bool counted = false;          // this handle is in g_live[device] (the budget of barrier grids, barrier_cap)
     double last_ll = NAN, last_g[3] = {NAN, NAN, NAN}, last_quad = NAN, last_logdet = NAN;
     // profiling
     int prof = 0;
@@ -172,7 +180,65 @@ void drain_kernel_events(cugp_gp* g)
 
 Batch B(const cugp_gp* g) { return g->grp ? g->grp->bt : Batch{}; }
 
-unsigned g_cfg_epoch = 1;          // bumped by cugp_set_tuning: captured graphs carry launch shapes
+// pinned host buffer the evaluation's results land in: the group's ([expert][8]) or the handle's.  Entries 0..5: LL, the
+// three gradients, y'K^-1y, log|K| (k_finalize); entry 6: set by a kernel whose bounded wait ran out (k_trtri_block)
+double* host_out(const cugp_gp* g) { return g->grp ? g->grp->hout : g->hout; }
+
+// ---- tuning: process defaults (cugp_set_tuning) under a lock, one copy per handle ----
+std::mutex g_tune_mu;
+int g_tune_default[TUNE_COUNT];
+bool g_tune_default_init = false;
+
+void tune_defaults_locked()
+{
+    if (!g_tune_default_init) {
+        for (int k = 0; k < TUNE_COUNT; k++) g_tune_default[k] = g_tune_init[k];
+        g_tune_default_init = true;
+    }
+}
+
+// Take the process defaults over into the handle (keys it owns excepted); called where an API call starts to
+// enqueue.  A changed launch shape invalidates the handle's captured graphs.
+void sync_tuning(cugp_gp* g)
+{
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    tune_defaults_locked();
+    bool changed = false;
+    for (int k = 0; k < TUNE_COUNT; k++)
+        if (!g->tune_own[k] && g->tune[k] != g_tune_default[k]) {
+            if (k != TUNE_GRAPHS) changed = true;
+            g->tune[k] = g_tune_default[k];
+        }
+    if (changed) g->cfg_epoch++;
+}
+
+// While an API call enqueues for handle g the launchers of kernels.hip read g's tuning (thread-local pointer).
+struct TuneScope {
+    const int* prev;
+    explicit TuneScope(cugp_gp* g) : prev(t_tune) { sync_tuning(g); t_tune = g->tune; }
+    ~TuneScope() { t_tune = prev; }
+};
+
+// ---- budget of barrier grids ----
+// k_trtri_block is a grid whose workgroups wait for each other: every launch of it needs all G of its workgroups
+// resident at once.  One launch is safe by construction (G <= 64, far below the 512 slots; workgroups of a launch are
+// dispatched in order), but launches of DIFFERENT handles interleave on the device: 9 handles x 64 workgroups exceed the
+// slots, every launch is partly resident and each waits for workgroups that cannot be dispatched (a stall of seconds,
+// then NaN results).  So the handles of a device share a budget of 384 barrier workgroups: each launch takes at most
+// 384 / (live handles on the device) -- 64 up to 6 handles, 16 at 24 -- and beyond 24 live handles the block's inverse
+// goes launch by launch (k_trtri_diag + k_trtri_level), which waits for nothing.  Stalled launches then hold fewer
+// than 384 of the 512 slots whatever the interleaving, so some launch always gets the workgroups it is missing.
+// (Per process: handles of other processes on the same GPU are not seen.)
+std::atomic<int> g_live[64];
+int barrier_cap(const cugp_gp* g)
+{
+    const int dev = g->device >= 0 && g->device < 64 ? g->device : 63;
+    int live = g_live[dev].load(std::memory_order_relaxed);
+    if (live < 1) live = 1;
+    if (live > 24) return 0;
+    const int cap = 384 / live;
+    return cap > TRTRI_BLOCK_MAXWG ? TRTRI_BLOCK_MAXWG : cap;
+}
 
 // block rows per hand-over to the other streams: about a sixteenth of the matrix, at least 2 tiles (interleaved
 // A/B at 16, 32, 64 and 79 tiles: 2, 2-3, 4, 5 were the best), single tiles up to 8 tiles (600 and 1000 rows: -9 %
@@ -180,29 +246,36 @@ unsigned g_cfg_epoch = 1;          // bumped by cugp_set_tuning: captured graphs
 int pipe_block(const cugp_gp* g, bool with_inverse)
 {
     const bool overlap = g->grp ? g->grp->overlap : g->overlap;
-    int w = (with_inverse && overlap) ? g_tune[TUNE_PIPE_BLOCK] : 0;
+    int w = (with_inverse && overlap) ? g->tune[TUNE_PIPE_BLOCK] : 0;
     if (w < 0) w = g->nt <= 8 ? 1 : ((g->nt + 8) / 16 > 2 ? (g->nt + 8) / 16 : 2);
     return w >= g->nt ? 0 : w;
 }
 
-// one timed launch (profiling level 2): event pair + bookkeeping
+// one timed launch: event pair + bookkeeping.  Levels 2 and 3 record an event in front of and behind the launch on its
+// stream; level 4 hands the pair to the launch itself (hipExtLaunchKernelGGL: the dispatch's own begin / end, no extra
+// packets on the stream -- the schedule of the timed pass, and the durations rocprofv3 --kernel-trace reports)
 struct TimedLaunch {
-    cugp_gp* g; hipStream_t s; bool on;
-    TimedLaunch(cugp_gp* g_, hipStream_t s_, bool want) : g(g_), s(s_), on(want && g_->kev_used + 2 <= (int)g_->kev.size())
+    cugp_gp* g; hipStream_t s; bool on, ext;
+    TimedLaunch(cugp_gp* g_, hipStream_t s_, bool want)
+        : g(g_), s(s_), on(want && g_->kev_used + 2 <= (int)g_->kev.size()), ext(g_->prof >= 4)
     {
-        if (on && hipEventRecord(g->kev[g->kev_used], s) != hipSuccess) on = false;
+        if (!on) return;
+        if (ext) time_next_launch(g->kev[g->kev_used], g->kev[g->kev_used + 1]);
+        else if (hipEventRecord(g->kev[g->kev_used], s) != hipSuccess) on = false;
     }
+    ~TimedLaunch() { if (on && ext && timing_pending()) time_next_launch(nullptr, nullptr); }   // the launch did not happen
     void done(int kind, double flop)
     {
         if (!on) return;
-        if (hipEventRecord(g->kev[g->kev_used + 1], s) != hipSuccess) return;
+        if (ext) { if (timing_pending()) return; }            // (armed but not consumed: nothing was launched)
+        else if (hipEventRecord(g->kev[g->kev_used + 1], s) != hipSuccess) return;
         g->kev_kind[g->kev_used / 2] = kind;
         g->kev_flopv[g->kev_used / 2] = flop;
         g->kev_used += 2;
     }
 };
 
-// is this launch one of the timed ones?  level 2: one in `every`, rotating with `phase`; level 3: all
+// is this launch one of the timed ones?  level 2: one in `every`, rotating with `phase`; levels 3 and 4: all
 bool sampled(const cugp_gp* g, int phase, int every) { return g->prof >= 3 || (g->prof == 2 && phase % every == 0); }
 
 // algorithmic flop of the inverse's tile products (multiply + add; a k tile that is triangular counts half).
@@ -249,10 +322,12 @@ double level_flop(int nt, int s, int step)
 int enqueue_block_own_inverse(cugp_gp* g, int a, int wb, hipStream_t o)
 {
     const int ld = g->npad;
-    if (wb <= TRTRI_BLOCK_MAX_TILES) {
+    const int gcap = barrier_cap(g);                         // this handle's share of the device's barrier workgroups; 0: none
+    if (wb <= TRTRI_BLOCK_MAX_TILES && gcap > 0) {
         unsigned* base = g->grp ? g->grp->tickets : g->dtickets;
         TimedLaunch tl(g, o, sampled(g, (a / (wb > 0 ? wb : 1)) + (int)g->eval_seq, 4));
-        launch_trtri_block(g->dA, g->d64, g->dT, g->dU, ld, a, wb, base + g->nt + a, g->dlogdet, g->nt + a, o, B(g));
+        launch_trtri_block(g->dA, g->d64, g->dT, g->dU, ld, a, wb, base + g->nt + a, g->dlogdet, g->nt + a, o, B(g), gcap,
+                           host_out(g));
         double fl = 0;
         for (int s = 1; s < wb; s *= 2) fl += level_flop(wb, s, 1) + level_flop(wb, s, 2);
         tl.done(KIND_BLOCK, fl);
@@ -386,13 +461,14 @@ int enqueue_last_block(cugp_gp* g, int a, int idx)
 int phase_mark(cugp_gp* g, int i);
 int fetch_eval(cugp_gp* g);
 
+
 // The shares of K^-1 on a stream of their own (beside the next block's bordering) or behind their block's bordering:
 // for a group of experts two large launches in flight fill each other's partly empty last rounds (-3...-6 % per
 // evaluation at 16x1500, 8x3000, 4x6000); for a single matrix the extra hand-over costs what it gains or more
 // (1500: +1.9 %, 6000: +3.3 %, 8192 / 10000: +-0.3 %, 16384: +0.7 %).  TUNE_LAUUM_STREAM: 0 never, 1 groups, 2 always.
 bool kinv_stream(const cugp_gp* g)
 {
-    const int v = g_tune[TUNE_LAUUM_STREAM];
+    const int v = g->tune[TUNE_LAUUM_STREAM];
     return v >= 2 || (v == 1 && g->grp != nullptr);
 }
 
@@ -474,8 +550,8 @@ StepPlan plan_step(int nt, int P, int near, int kb)
 // panel width of the look-ahead factorisation for this handle (1 = classic right-looking, K = 128 per pass)
 int panel_width(const cugp_gp* g)
 {
-    int P = g_tune[TUNE_PANEL];
-    if (P < 2 || g->nt < g_tune[TUNE_PANEL_MIN_NT] || g->nt < 3 * P) return 1;
+    int P = g->tune[TUNE_PANEL];
+    if (P < 2 || g->nt < g->tune[TUNE_PANEL_MIN_NT] || g->nt < 3 * P) return 1;
     return P > 32 ? 32 : P;
 }
 
@@ -507,7 +583,7 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false, const unsign
     const int nt = g->nt, ld = g->npad;
     const int w = pipe_block(g, with_inverse);
     const int P = panel_width(g);
-    const int near = g_tune[TUNE_NEAR_TILES];
+    const int near = g->tune[TUNE_NEAR_TILES];
     hipStream_t m = g->stream;                              // the whole factorisation is ordered on the handle's stream
     int nblk = 0, done = 0;                                 // blocks forked so far, block rows handed over
     struct Fork { int a, b; };
@@ -542,7 +618,7 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false, const unsign
         // (look-ahead form: plain stores -- the panel solve that follows reads the column at once, and reading
         //  freshly non-temporally stored tiles took it 50 us instead of 16)
         launch_syrk_step(g->dA, ld, kb, nt, g->d16, g->d64, g->dlogdet, g->dtickets, m, B(g), sp.wcol,
-                         P > 1 ? g_tune[TUNE_STEP_STREAM] : 1);
+                         P > 1 ? g->tune[TUNE_STEP_STREAM] : 1);
         tl.done(KIND_STEP, trailing_flop(nt, kb + 1, kb + 1 + sp.wcol, 1));
         if (hand_over) {
             // The block's own 6-8 launches take the host 15-35 us.  Where a chain step is shorter than that (small
@@ -581,9 +657,6 @@ int enqueue_trtri(cugp_gp* g)
     HIPCHK(hipGetLastError());
     return CUGP_OK;
 }
-
-// pinned host buffer the evaluation's results land in: the group's ([expert][8]) or the handle's
-double* host_out(const cugp_gp* g) { return g->grp ? g->grp->hout : g->hout; }
 
 int phase_mark(cugp_gp* g, int i)
 {
@@ -636,6 +709,7 @@ int enqueue_eval(cugp_gp* g, bool want_grad)
     int rc;
     if (!g->have_data) return fail(CUGP_ERR_INVALID, "no training data set (cugp_set_data)");
     if ((rc = fetch_eval(g))) return rc;                      // one evaluation in flight per handle
+    TuneScope ts(g);
     if ((rc = use_device(g))) return rc;
     if ((rc = ensure_factor_bufs(g))) return rc;
     if (want_grad && (rc = ensure_inverse_bufs(g))) return rc;
@@ -646,14 +720,14 @@ int enqueue_eval(cugp_gp* g, bool want_grad)
     // Replay a captured graph when the evaluation is a single-stream sequence (no hand-over to the other
     // streams) and nothing is being timed; otherwise enqueue the launches one by one.
     // (measured: 16 x 1500 rows 4.7 -> 4.1 ms, 2 x 1500 rows 1.25 -> 1.18 ms; nothing to gain above ~3000 rows)
-    const bool graph = g_tune[TUNE_GRAPHS] != 0 && g->prof == 0 && g->nt <= GRAPH_MAX_TILES &&
+    const bool graph = g->tune[TUNE_GRAPHS] != 0 && g->prof == 0 && g->nt <= GRAPH_MAX_TILES &&
                        pipe_block(g, want_grad) == 0;
     if (!graph) {
         if ((rc = record_eval(g, want_grad, nullptr))) return rc;
     } else {
         const int gi = want_grad ? 1 : 0;
         *g->hhs = scalars(g);
-        if (!g->gexec[gi] || g->gepoch[gi] != g_cfg_epoch) {
+        if (!g->gexec[gi] || g->gepoch[gi] != g->cfg_epoch) {
             if (g->gexec[gi]) (void)hipGraphExecDestroy(g->gexec[gi]);
             g->gexec[gi] = nullptr;
             prepare_kernels();
@@ -668,7 +742,7 @@ int enqueue_eval(cugp_gp* g, bool want_grad)
             const hipError_t ei = hipGraphInstantiate(&g->gexec[gi], graph_obj, nullptr, nullptr, 0);
             (void)hipGraphDestroy(graph_obj);
             if (ei != hipSuccess) { g->gexec[gi] = nullptr; return fail(CUGP_ERR_DEVICE, "hipGraphInstantiate", ei); }
-            g->gepoch[gi] = g_cfg_epoch;
+            g->gepoch[gi] = g->cfg_epoch;
         }
         HIPCHK(hipGraphLaunch(g->gexec[gi], g->stream));
     }
@@ -687,6 +761,7 @@ int enqueue_continue(cugp_gp* g)
     int rc;
     if ((rc = fetch_eval(g))) return rc;
     if (!g->factor_valid) return fail(CUGP_ERR_INVALID, "no valid factor to continue from");
+    TuneScope ts(g);
     if ((rc = use_device(g))) return rc;
     if ((rc = ensure_inverse_bufs(g))) return rc;
     if (const int pe = prepare_kernels())
@@ -714,6 +789,16 @@ int fetch_eval(cugp_gp* g)
     if ((rc = use_device(g))) return rc;
     HIPCHK(hipStreamSynchronize(g->stream));
     g->pending = false;
+    if (g->hout[6] != 0.0) {
+        // a bounded wait inside a kernel ran out (k_trtri_block's stage barrier): nothing of this evaluation is to be
+        // trusted, and nothing of it is kept -- the next call starts from the covariance build
+        g->hout[6] = 0.0;
+        g->factor_valid = g->inverse_valid = false;
+        g->last_ll = g->last_quad = g->last_logdet = NAN;
+        g->last_g[0] = g->last_g[1] = g->last_g[2] = NAN;
+        if (g->prof >= 2) drain_kernel_events(g);
+        return fail(CUGP_ERR_DEVICE, "a stage barrier of k_trtri_block ran out of polls (the evaluation was abandoned; results NaN)");
+    }
     g->last_ll = g->hout[0];
     g->last_quad = g->hout[4];
     g->last_logdet = g->hout[5];
@@ -760,16 +845,23 @@ int cugp_create_padded(int n, int d, int device, int npad_min, cugp_gp** out)
     g->npad = g->nt * TILE;
     g->nblocks_trace = trace_num_blocks(g->npad);
     *out = nullptr;
+    {   // the process defaults as they stand now
+        std::lock_guard<std::mutex> lk(g_tune_mu);
+        tune_defaults_locked();
+        for (int k = 0; k < TUNE_COUNT; k++) g->tune[k] = g_tune_default[k];
+    }
+    g_live[device < 64 ? device : 63].fetch_add(1, std::memory_order_relaxed);
+    g->counted = true;
     hipError_t e = hipSetDevice(device);
     // default priority everywhere: prioritised streams share few hardware queues, which serialises the
     // experts of a BCM evaluated on one device
     // (TUNE_STREAM_PRIO, an A/B hook: the factorisation's stream at the highest and / or the inverse streams at the
     //  lowest priority)
     int plo = 0, phi = 0;
-    if (e == hipSuccess && g_tune[TUNE_STREAM_PRIO] != 0) e = hipDeviceGetStreamPriorityRange(&plo, &phi);
-    const int pmain = (g_tune[TUNE_STREAM_PRIO] & 1) ? phi : 0, pinv = (g_tune[TUNE_STREAM_PRIO] & 2) ? plo : 0;
+    if (e == hipSuccess && g->tune[TUNE_STREAM_PRIO] != 0) e = hipDeviceGetStreamPriorityRange(&plo, &phi);
+    const int pmain = (g->tune[TUNE_STREAM_PRIO] & 1) ? phi : 0, pinv = (g->tune[TUNE_STREAM_PRIO] & 2) ? plo : 0;
     auto mkstream = [&](hipStream_t* s, int prio) {
-        return g_tune[TUNE_STREAM_PRIO] != 0 ? hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio)
+        return g->tune[TUNE_STREAM_PRIO] != 0 ? hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio)
                                              : hipStreamCreateWithFlags(s, hipStreamNonBlocking);
     };
     if (e == hipSuccess) e = mkstream(&g->stream, pmain);
@@ -792,6 +884,7 @@ int cugp_create_padded(int n, int d, int device, int npad_min, cugp_gp** out)
     if (e == hipSuccess) e = hipMalloc((void**)&g->dout, 8 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&g->dtickets, (size_t)2 * g->nt * sizeof(unsigned));
     if (e == hipSuccess) e = hipHostMalloc((void**)&g->hout, 8 * sizeof(double), hipHostMallocDefault);
+    if (e == hipSuccess) memset(g->hout, 0, 8 * sizeof(double));   // (entry 6 is the status word fetch_eval reads)
     if (e == hipSuccess) e = hipHostMalloc((void**)&g->hhs, sizeof(HyperScalars), hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc((void**)&g->dhs, sizeof(HyperScalars));
     for (int i = 0; i <= NPHASE && e == hipSuccess; i++) e = hipEventCreate(&g->pev[i]);
@@ -807,6 +900,7 @@ int cugp_create_padded(int n, int d, int device, int npad_min, cugp_gp** out)
 int cugp_destroy(cugp_gp* g)
 {
     if (!g) return CUGP_OK;
+    if (g->counted) g_live[g->device >= 0 && g->device < 64 ? g->device : 63].fetch_sub(1, std::memory_order_relaxed);
     (void)hipSetDevice(g->device);
     if (g->stream) (void)hipStreamSynchronize(g->stream);
     if (g->aux) (void)hipStreamSynchronize(g->aux);
@@ -989,7 +1083,14 @@ static int predict_device(cugp_gp* g, const double* Xt, int nt, double** dmean_o
     double* dv = dm + nv;
     HIPCHK(hipMemcpyAsync(dXt, Xt, (size_t)nt * g->d * sizeof(double), hipMemcpyHostToDevice, g->stream));
     launch_kcross(g->dX, g->n, g->d, g->npad, dXt, nt, ntpad, h, dKs, g->stream);
-    launch_predict_gemm(dKs, g->dT, dW, g->npad, ntpad / TILE, g->nt, g->stream);
+    {
+        // W = Ks L^-T: test tile tt, row tile ti sums k <= ti (the diagonal k tile of T is triangular: counted half)
+        TimedLaunch tl(g, g->stream, g->prof >= 3);
+        launch_predict_gemm(dKs, g->dT, dW, g->npad, ntpad / TILE, g->nt, g->stream);
+        double kt = 0;
+        for (int ti = 0; ti < g->nt; ti++) kt += ti + 0.5;
+        tl.done(KIND_PREDICT, kt * (ntpad / TILE) * 2.0 * TILE * TILE * TILE);
+    }
     launch_predict_finish(dKs, dW, g->dalpha, g->n, g->npad, nt, h, dm, dv, g->stream);
     HIPCHK(hipGetLastError());
     *dmean_out = dm;
@@ -1008,6 +1109,7 @@ int cugp_predict(cugp_gp* g, const double* Xt, int nt, double* mean, double* var
         if (e == hipSuccess) e = hipMemcpyAsync(var, dv, (size_t)nt * sizeof(double), hipMemcpyDeviceToHost, g->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
         if (e != hipSuccess) rc = fail(CUGP_ERR_DEVICE, "cugp_predict copy", e);
+        else if (g->prof >= 2) drain_kernel_events(g);
     }
     (void)hipStreamSynchronize(g->stream);
     for (double* p : tmp) (void)hipFree(p);
@@ -1143,8 +1245,10 @@ int la_handle(int n, const double* K, const double* y, int device, cugp_gp** out
 int la_factor_inverse(cugp_gp* g, bool inverse)
 {
     int rc;
+    TuneScope ts(g);
     if ((rc = enqueue_potrf(g, inverse))) return rc;
     HIPCHK(hipStreamSynchronize(g->stream));
+    if (g->hout[6] != 0.0) { g->hout[6] = 0.0; return fail(CUGP_ERR_DEVICE, "a stage barrier of k_trtri_block ran out of polls"); }
     g->factor_valid = true;
     g->inverse_valid = inverse;
     return CUGP_OK;
@@ -1179,6 +1283,7 @@ static int la_solve(int n, const double* K, const double* y, double* x, double* 
     cugp_gp* g = nullptr;
     int rc = la_handle(n, K, y, device, &g);
     if (rc) return rc;
+    TuneScope ts(g);
     if (!(rc = enqueue_potrf(g, false)) && !(rc = enqueue_trtri(g))) {
         launch_trmv_lower(g->dT, g->npad, g->npad, g->dy, g->dz, g->stream);
         launch_trmv_upper(g->dU, g->npad, g->npad, g->dz, g->dalpha, g->stream);
@@ -1320,11 +1425,38 @@ int cugp_rprop_solve(cugp_gp* g, int iters, double* trace, int trace_cap, int* n
 }
 
 // ---------------------------------------------------------------- test hooks
+// Process default of one tuning key.  Thread-safe (a lock); a handle takes the defaults over when it next starts to
+// enqueue -- an evaluation already enqueued keeps the shapes it was enqueued with -- except for the keys set for that
+// handle alone with cugp_set_handle_tuning.
 int cugp_set_tuning(int key, int value)
 {
     if (key < 0 || key >= TUNE_COUNT) return CUGP_ERR_INVALID;
-    if (g_tune[key] != value && key != TUNE_GRAPHS) g_cfg_epoch++;   // launch shapes changed: recapture graphs
-    g_tune[key] = value;
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    tune_defaults_locked();
+    g_tune_default[key] = value;
+    return CUGP_OK;
+}
+
+// One key for ONE handle (no other handle, and no later cugp_set_tuning, changes it); own = 0 hands the key back to the
+// process default.  The handle's owner thread calls it, like every other call on the handle.
+int cugp_set_handle_tuning(cugp_gp* g, int key, int value, int own)
+{
+    if (!g || key < 0 || key >= TUNE_COUNT) return CUGP_ERR_INVALID;
+    int rc;
+    if ((rc = fetch_eval(g))) return rc;
+    g->tune_own[key] = own != 0;
+    if (own && g->tune[key] != value) {
+        g->tune[key] = value;
+        if (key != TUNE_GRAPHS) g->cfg_epoch++;
+    }
+    return CUGP_OK;
+}
+
+int cugp_get_handle_tuning(cugp_gp* g, int key, int* value)
+{
+    if (!g || !value || key < 0 || key >= TUNE_COUNT) return CUGP_ERR_INVALID;
+    sync_tuning(g);
+    *value = g->tune[key];
     return CUGP_OK;
 }
 
@@ -1384,6 +1516,7 @@ int cugp_bench_la_check(int op, int n, int device, int reps, double* ms, double*
     hipError_t e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
     double best = 1e300;
+    TuneScope ts(g);
     for (int r = 0; r < reps + 1 && e == hipSuccess && rc == CUGP_OK; r++) {
         launch_kbuild(g->dX, g->n, g->d, g->npad, scalars(g), g->dA, op == 4, g->stream);
         if (op == 1 || op == 2) rc = enqueue_potrf(g, false);
@@ -1472,6 +1605,7 @@ int cugp_group_create(cugp_gp* const* experts, int k, cugp_group** out)
     if (e == hipSuccess) e = hipMalloc((void**)&gr->ctx.tickets, (size_t)k * 2 * nt * sizeof(unsigned));
     if (e == hipSuccess) e = hipMalloc((void**)&gr->ctx.dout, (size_t)k * 8 * sizeof(double));
     if (e == hipSuccess) e = hipHostMalloc((void**)&gr->ctx.hout, (size_t)k * 8 * sizeof(double), hipHostMallocDefault);
+    if (e == hipSuccess) memset(gr->ctx.hout, 0, (size_t)k * 8 * sizeof(double));   // (entry 6 of a row: status word)
     if (e != hipSuccess) {
         cugp_group_destroy(gr);
         return fail(e == hipErrorOutOfMemory ? CUGP_ERR_NOMEM : CUGP_ERR_DEVICE, "cugp_group_create", e);
@@ -1507,7 +1641,8 @@ int cugp_group_enqueue(cugp_group* gr, int want_grad)
     const int k = (int)gr->experts.size(), nt = lead->nt;
     int rc;
     if (gr->pending) return fail(CUGP_ERR_BUSY, "cugp_group_enqueue: an evaluation is already in flight");
-    if (nt > g_tune[TUNE_GROUP_MAX_TILES]) return CUGP_ERR_INVALID;
+    TuneScope ts(lead);                                       // the group runs on the lead expert's tuning
+    if (nt > lead->tune[TUNE_GROUP_MAX_TILES]) return CUGP_ERR_INVALID;
     // the batched step kernel puts its workgroups on gridDim.y (65535 at most): larger experts go one by one
     if ((long long)nt * (nt + 1) / 2 + 16 > 65535) return CUGP_ERR_INVALID;
     for (cugp_gp* e : gr->experts) {
@@ -1538,13 +1673,13 @@ int cugp_group_enqueue(cugp_group* gr, int want_grad)
     }
     for (cugp_gp* e : gr->experts) e->factor_valid = e->inverse_valid = false;
     *lead->hhs = scalars(lead);
-    gr->ctx.overlap = g_tune[TUNE_GROUP_OVERLAP] != 0;
+    gr->ctx.overlap = lead->tune[TUNE_GROUP_OVERLAP] != 0;
     lead->grp = &gr->ctx;
     const int gi = want_grad ? 1 : 0;
     // (with the hand-over the sequence spans several streams: enqueued launch by launch, not replayed)
-    if (g_tune[TUNE_GRAPHS] != 0 && nt <= GRAPH_MAX_TILES && pipe_block(lead, want_grad != 0) == 0 &&
+    if (lead->tune[TUNE_GRAPHS] != 0 && nt <= GRAPH_MAX_TILES && pipe_block(lead, want_grad != 0) == 0 &&
         panel_width(lead) == 1) {
-        if (!gr->gexec[gi] || gr->gepoch[gi] != g_cfg_epoch) {
+        if (!gr->gexec[gi] || gr->gepoch[gi] != lead->cfg_epoch) {
             if (gr->gexec[gi]) (void)hipGraphExecDestroy(gr->gexec[gi]);
             gr->gexec[gi] = nullptr;
             hipGraph_t graph_obj = nullptr;
@@ -1559,7 +1694,7 @@ int cugp_group_enqueue(cugp_group* gr, int want_grad)
                 lead->grp = nullptr;
                 return rc ? rc : fail(CUGP_ERR_DEVICE, "group graph capture", e);
             }
-            gr->gepoch[gi] = g_cfg_epoch;
+            gr->gepoch[gi] = lead->cfg_epoch;
         }
         rc = CUGP_OK;
         const hipError_t e = hipGraphLaunch(gr->gexec[gi], lead->stream);
@@ -1584,6 +1719,17 @@ int cugp_group_fetch(cugp_group* gr, double* ll, double* g)
     if ((rc = use_device(lead))) return rc;
     HIPCHK(hipStreamSynchronize(lead->stream));
     gr->pending = false;
+    bool timed_out = false;
+    for (int i = 0; i < k; i++)
+        if (gr->ctx.hout[(size_t)i * 8 + 6] != 0.0) { gr->ctx.hout[(size_t)i * 8 + 6] = 0.0; timed_out = true; }
+    if (timed_out) {                                          // (see fetch_eval)
+        for (cugp_gp* e : gr->experts) {
+            e->factor_valid = e->inverse_valid = false;
+            e->last_ll = e->last_quad = e->last_logdet = NAN;
+            e->last_g[0] = e->last_g[1] = e->last_g[2] = NAN;
+        }
+        return fail(CUGP_ERR_DEVICE, "a stage barrier of k_trtri_block ran out of polls (the group's evaluation was abandoned)");
+    }
     for (int i = 0; i < k; i++) {
         cugp_gp* e = gr->experts[i];
         const double* h = gr->ctx.hout + (size_t)i * 8;

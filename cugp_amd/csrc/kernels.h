@@ -7,8 +7,10 @@ namespace cugp {
 
 constexpr int TILE = 128;          // tile edge of every fp64 MFMA product and of the padded leading dimension
 
-// launch-shape thresholds, adjustable at run time for A/B tuning (cugp_set_tuning).  Process-wide and NOT thread-safe:
-// a bench / test hook, to be set while no other thread is inside the library (handles read it while they enqueue).
+// launch-shape thresholds, adjustable at run time for A/B tuning.  Every handle carries its own copy (cugp_gp::tune):
+// cugp_set_tuning changes the process defaults under a lock, a handle takes them over when it next enqueues (keys set
+// with cugp_set_handle_tuning stay as set), and the launchers below read the copy of the handle whose API call is running
+// on this thread (t_tune) -- so handles driven from different threads never see each other's settings change mid-call.
 enum { TUNE_LAUUM_WM2_MAX = 0,   // K^-1 product: use 64x64 tiles when there are at most this many 128-tiles
        TUNE_TRTRI_WM2_MAX = 1,   // inverse level: same rule
        TUNE_SYRK_REM_MAX = 2,    // trailing update: split the last partial round into 64x64 quarters when it has at most this many tiles
@@ -25,8 +27,12 @@ enum { TUNE_LAUUM_WM2_MAX = 0,   // K^-1 product: use 64x64 tiles when there are
        TUNE_SPLIT_REM_MAX = 13,  // uniform-K launches (block-wise K^-1 share, bordering, wide update): a last round of at most this many tiles runs as 64x64 quarters
        TUNE_STEP_QUARTER_MAX = 14, // step kernel: launches of at most this many 64x64 workgroups run ALL their tiles as quarters (chain-bound tail)
        TUNE_STREAM_PRIO = 15,    // read when a handle is created: bit 0 = the factorisation's stream at the highest priority, bit 1 = the inverse streams at the lowest (default 0: prioritised streams serialised grouped experts in round 3)
-       TUNE_COUNT = 16 };
-extern int g_tune[TUNE_COUNT];
+       TUNE_BARRIER_SPIN = 16,   // polls a workgroup of k_trtri_block spends at a stage barrier before it gives up (the evaluation then fails with CUGP_ERR_DEVICE instead of hanging); 0 = give up at once (test hook)
+       TUNE_CHAIN = 17,          // the factorisation's chain as one resident launch beside the off-chain launches (0 = two launches per step)
+       TUNE_COUNT = 18 };
+extern const int g_tune_init[TUNE_COUNT];     // built-in defaults
+extern thread_local const int* t_tune;        // the tuning the launchers on this thread read (a handle's copy, or the built-in defaults)
+inline int tune(int key) { return t_tune[key]; }
 
 struct HyperScalars;
 
@@ -54,7 +60,8 @@ struct HyperScalars {              // exp(2*theta) evaluated on the host, as the
 // hd (optional, also below): read the hyper-scalars from device memory instead of the argument
 void launch_kbuild(const double* X, int n, int d, int npad, HyperScalars h, double* K, bool full,
                    hipStream_t s, const HyperScalars* hd = nullptr, Batch bt = {}, unsigned* tickets = nullptr);
-                   // tickets: the factorisation's arrival counters (npad/128 per expert), zeroed by the launch when given
+                   // tickets: the factorisation's arrival counters -- 2 * npad/128 per expert ([0, nt) the step tickets of
+                   // k_syrk_step, [nt, 2 nt) the stage counters of k_trtri_block) --, zeroed by the launch when given
 // S[i][j] = |x_i - x_j|^2 / c, zero diagonal, full symmetric (N2, covkernel.cpp:130-157)
 void launch_sqdist(const double* X, int n, int d, int npad, double c, double* S, hipStream_t s);
 // Ks[t][i] = sf2 * exp(-0.5*|x_i - xt_t|^2 / l^2), row-major nt_pad x npad (pad = 0)   (N12)
@@ -71,9 +78,14 @@ void launch_trtri_diag(const double* A, int ld, int kb, int nblocks, const doubl
 // inverse of the hand-over block of rows [a, a + wb) in one launch: diagonal-tile inverses + every doubling level inside
 // the block (k_trtri_block; wb <= TRTRI_BLOCK_MAX_TILES).  ctr: the block's stage counter (zero before the launch; batched:
 // tickets[ctr_off] of every expert); poison: log-determinant shares (entry a becomes NaN if a stage wait ran out)
+// gcap: most workgroups the launch may hold at its stage barriers (the caller's share of the device's budget for
+// barrier grids, cugp_capi.cpp: barrier_cap); hstat: pinned host word ([expert][8] doubles, entry 6) that is set when a
+// stage wait ran out -- the evaluation's fetch then returns CUGP_ERR_DEVICE
 constexpr int TRTRI_BLOCK_MAX_TILES = 16;
+constexpr int TRTRI_BLOCK_MAXWG = 64;
 int launch_trtri_block(const double* L, const double* d64, double* T, double* U, int ld, int a, int wb, unsigned* ctr,
-                       double* poison, int ctr_off, hipStream_t s, Batch bt = {});
+                       double* poison, int ctr_off, hipStream_t s, Batch bt = {}, int gcap = TRTRI_BLOCK_MAXWG,
+                       double* hstat = nullptr);
 // trailing update of step kb fused with the factorisation of diagonal block kb+1 (tickets[kb] must be 0)
 // wcol > 0: only the tile columns [kb+1, kb+1+wcol) (two-speed form: the near window)
 void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* d64, double* logdet_part,
@@ -118,6 +130,10 @@ void launch_trace(const double* X, int n, int d, int npad, HyperScalars h, const
 void launch_finalize(const double* z, int npad, int n, const double* logdet_part, int nt, const double* part,
                      int nblocks, HyperScalars h, double* out, double* hout, hipStream_t s,
                      const HyperScalars* hd = nullptr, Batch bt = {});   // hout: pinned host copy of the results ([expert][8]) or null
+// profiling level 4: the NEXT launch of a timed kernel (trailing updates, inverse products, k_trtri_block,
+// k_predict_gemm) on this thread carries these events as the dispatch's own start / stop (hipExtLaunchKernelGGL)
+void time_next_launch(hipEvent_t start, hipEvent_t stop);
+bool timing_pending();   // still armed: the launch it was meant for did not happen
 // per-device function attributes (dynamic LDS sizes) for the current device; the launchers do it lazily, a
 // stream capture must not.  Returns the hipError_t of a failed hipFuncSetAttribute (0 = fine).
 int prepare_kernels();

@@ -27,6 +27,7 @@
 #include "kernels.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdlib>
 
@@ -301,6 +302,40 @@ __device__ __forceinline__ void tile_store(double* __restrict__ C, int ldc, cons
             }
 }
 
+// C += SIGN * acc, the C tile read in the EPILOGUE (round 5).  The accumulators start from zero and the K loop runs
+// first; then one row group m of the wave at a time -- 16 doubles per lane in flight -- is read, updated and written.
+// The product form (acc = C in front of the K loop, tile_load) held the first MFMA back until all 128 KB of the tile
+// had arrived, in a burst with the launch's other workgroups and with the first operand stage; here the K loop starts
+// at once and the C traffic of a workgroup overlaps the K loop of the other workgroup on its CU.  Measured
+// (tools/wide_bench.hip, trailing-update form, 1596 tiles): K = 256 52.8 -> 54.7 TF/s, K = 512 56.4 -> 59.3, K = 1024
+// 59.0 -> 61.4, K = 2048 54.4 -> 56.3, K = 128 44.6 -> 45.2; with neither read nor write 61.4 / 62.5 / 62.9 / 56.9 /
+// 59.2.  Plain accesses: non-temporal ones lost 1-3 TF/s in this form.  One more rounding per entry and pass than the
+// product form (the sum is formed first, then added), for every kernel alike.
+template <int SIGN, int WM>
+__device__ __forceinline__ void tile_accum_store(double* __restrict__ C, int ldc, const d4 (&acc)[WM][WM])
+{
+    const int tid = opaque_tid();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+#pragma unroll
+    for (int m = 0; m < WM; m++) {
+        d2 v[4][WM / 2];
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int np = 0; np < WM / 2; np++)
+                v[r][np] = *(const d2*)(C + (size_t)ACC_ROW(m, r) * ldc + ACC_COL2(np));
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int np = 0; np < WM / 2; np++) {
+                d2* dst = (d2*)(C + (size_t)ACC_ROW(m, r) * ldc + ACC_COL2(np));
+                if (SIGN > 0) *dst = (d2){v[r][np][0] + acc[m][2 * np][r], v[r][np][1] + acc[m][2 * np + 1][r]};
+                else *dst = (d2){v[r][np][0] - acc[m][2 * np][r], v[r][np][1] - acc[m][2 * np + 1][r]};
+            }
+    }
+}
+
 // Ct[col][row] = alpha*acc  (transposed store).  The tile is turned through LDS (free after the K loop)
 // in two halves of 16*WM rows so that global stores are whole runs of that many doubles; the LDS image
 // [col][16*WM rows] is XOR-swizzled on the row index so the accumulator-layout writes do not pile onto
@@ -376,11 +411,11 @@ __device__ __forceinline__ void lauum_tile(const double* __restrict__ U, double*
     const int si = (sub / SUB) * BT, sj = (sub % SUB) * BT;
     double* C = Kinv + (size_t)(ti * TILE + si) * ld + tj * TILE + sj;
     d4 acc[WM][WM];
-    if (ti < a) tile_load<true>(C, ld, acc);           // rows of earlier blocks: add this block's share
-    else acc_zero(acc);
+    acc_zero(acc);
     tile_nt<false>(U + (size_t)(ti * TILE + si) * ld, ld, U + (size_t)(tj * TILE + sj) * ld, ld,
                    (ti < a ? a : ti) * TILE, (a + w) * TILE, acc, smem);
-    tile_store(C, ld, acc, 1.0);
+    if (ti < a) tile_accum_store<1>(C, ld, acc);       // rows of earlier blocks: add this block's share
+    else tile_store(C, ld, acc, 1.0);
 }
 
 // nfull (WM = 4 only): the first nfull tiles as 128x128 workgroups, the rest -- a last, partly empty round of 512
@@ -418,11 +453,11 @@ __device__ __forceinline__ void trtri_tile(const double* __restrict__ L, double*
     if (step == 1) {
         // Wt(tj, ti) rows in A's tile tj, columns in B's tile ti
         double* W = T + (size_t)(tj * TILE + si) * ld + ti * TILE + sj;
-        if (accumulate) tile_load(W, ld, acc);
-        else acc_zero(acc);
+        acc_zero(acc);
         tile_nt<false>(U + (size_t)(tj * TILE + si) * ld, ld, L + (size_t)(ti * TILE + sj) * ld, ld, kbeg * TILE,
                        kend * TILE, acc, smem);
-        tile_store(W, ld, acc, 1.0);
+        if (accumulate) tile_accum_store<1>(W, ld, acc);
+        else tile_store(W, ld, acc, 1.0);
     } else {
         acc_zero(acc);
         tile_nt<true>(T + (size_t)(ti * TILE + si) * ld, ld, T + (size_t)(tj * TILE + sj) * ld, ld, kbeg * TILE,
@@ -1569,6 +1604,10 @@ __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, in
     __shared__ double red[TILE + 4 * MT];
     __shared__ unsigned s_ticket;
     if (bid < NDIAGWG) {
+        // (timing experiments only, TUNE_CHAIN bits 0x200 / 0x100 -> stream_c bits 4 / 2: the chain without its diagonal
+        //  update / without the diagonal block's factorisation -- results are garbage, the evaluation's time says what
+        //  a faster chain could win at most)
+        if (stream_c & 4) return;
         // the factorisation's serial chain: win instruction issue over the product waves sharing the SIMD
         // (this launch's own tiles and the inverse blocks running on the other streams)
         __builtin_amdgcn_s_setprio(3);
@@ -1589,6 +1628,7 @@ __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, in
             s_ticket = __hip_atomic_fetch_add(&tickets[kb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if (s_ticket != NDIAGWG - 1) return;           // not the last arriver
+        if (stream_c & 2) return;                      // (timing experiment, see above)
         // (the last arriver reads the 36 micro tiles with agent-scope loads: potf2_body<true>, no acquire fence)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int kn = kb + 1;
@@ -1614,20 +1654,18 @@ __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, in
         trap_index((kb & 1) ? nfull + 1 - tlin : tlin, wcol, ti, tj);   // tile 0 = (kb+1,kb+1) is the diagonal one
         const int i0 = (kb + 1 + ti) * TILE, j0 = (kb + 1 + tj) * TILE;
         d4 acc[4][4];
-        if (stream_c) tile_load<true>(A + (size_t)i0 * ld + j0, ld, acc);
-        else tile_load<false>(A + (size_t)i0 * ld + j0, ld, acc);
-        tile_nt<true>(A + (size_t)i0 * ld, ld, A + (size_t)j0 * ld, ld, kb * TILE, (kb + 1) * TILE, acc, (char*)sm);
-        if (stream_c) tile_store<true>(A + (size_t)i0 * ld + j0, ld, acc, 1.0);
-        else tile_store<false>(A + (size_t)i0 * ld + j0, ld, acc, 1.0);
+        acc_zero(acc);
+        tile_nt<false>(A + (size_t)i0 * ld, ld, A + (size_t)j0 * ld, ld, kb * TILE, (kb + 1) * TILE, acc, (char*)sm);
+        tile_accum_store<-1>(A + (size_t)i0 * ld + j0, ld, acc);
     } else {
         int ti, tj;
         const int y = x - nfull;
         trap_index(nfull + 1 + (y >> 2), wcol, ti, tj);
         const int i0 = (kb + 1 + ti) * TILE + ((y >> 1) & 1) * 64, j0 = (kb + 1 + tj) * TILE + (y & 1) * 64;
         d4 acc[2][2];
-        tile_load<true>(A + (size_t)i0 * ld + j0, ld, acc);
-        tile_nt<true>(A + (size_t)i0 * ld, ld, A + (size_t)j0 * ld, ld, kb * TILE, (kb + 1) * TILE, acc, (char*)sm);
-        tile_store<true>(A + (size_t)i0 * ld + j0, ld, acc, 1.0);
+        acc_zero(acc);
+        tile_nt<false>(A + (size_t)i0 * ld, ld, A + (size_t)j0 * ld, ld, kb * TILE, (kb + 1) * TILE, acc, (char*)sm);
+        tile_accum_store<-1>(A + (size_t)i0 * ld + j0, ld, acc);
     }
 }
 
@@ -1652,9 +1690,9 @@ __global__ __launch_bounds__(256, 2) void k_syrk_wide(double* __restrict__ A, in
         trap_index(nfull + (y >> 2), cb - ca, ti, tj);
         const int i0 = (ca + ti) * TILE + ((y >> 1) & 1) * 64, j0 = (ca + tj) * TILE + (y & 1) * 64;
         d4 acc[2][2];
-        tile_load<true>(A + (size_t)i0 * ld + j0, ld, acc);
-        tile_nt<true>(A + (size_t)i0 * ld, ld, A + (size_t)j0 * ld, ld, k0 * TILE, (k0 + kw) * TILE, acc, smem);
-        tile_store<true>(A + (size_t)i0 * ld + j0, ld, acc, 1.0);
+        acc_zero(acc);
+        tile_nt<false>(A + (size_t)i0 * ld, ld, A + (size_t)j0 * ld, ld, k0 * TILE, (k0 + kw) * TILE, acc, smem);
+        tile_accum_store<-1>(A + (size_t)i0 * ld + j0, ld, acc);
         return;
     }
     // every XCD (workgroups are dealt round-robin over the 8 of them) walks one contiguous run of the row-major
@@ -1666,9 +1704,9 @@ __global__ __launch_bounds__(256, 2) void k_syrk_wide(double* __restrict__ A, in
     trap_index(rev ? nfull - 1 - tlin : tlin, cb - ca, ti, tj);
     const int i0 = (ca + ti) * TILE, j0 = (ca + tj) * TILE;
     d4 acc[4][4];
-    tile_load<true>(A + (size_t)i0 * ld + j0, ld, acc);
-    tile_nt<true>(A + (size_t)i0 * ld, ld, A + (size_t)j0 * ld, ld, k0 * TILE, (k0 + kw) * TILE, acc, smem);
-    tile_store<true>(A + (size_t)i0 * ld + j0, ld, acc, 1.0);
+    acc_zero(acc);
+    tile_nt<false>(A + (size_t)i0 * ld, ld, A + (size_t)j0 * ld, ld, k0 * TILE, (k0 + kw) * TILE, acc, smem);
+    tile_accum_store<-1>(A + (size_t)i0 * ld + j0, ld, acc);
 }
 
 // inverse of a 128x128 diagonal factor block from the two 64x64 inverses potf2 left in d64 (one doubling
@@ -1757,18 +1795,20 @@ __global__ __launch_bounds__(256) void k_trtri_diag(const double* __restrict__ A
 // back NaN instead of hanging the device).
 // ------------------------------------------------------------------------------------------
 constexpr int TRTRI_BLOCK_LDS = TRTRI_LDS > Geo<2>::LDS ? TRTRI_LDS : Geo<2>::LDS;
-constexpr int TRTRI_BLOCK_MAXWG = 64;
 
-__device__ __forceinline__ bool stage_barrier(unsigned* __restrict__ ctr, unsigned target)
+__device__ __forceinline__ bool stage_barrier(unsigned* __restrict__ ctr, unsigned target, unsigned spin_cap)
 {
     __shared__ int s_ok;
-    __syncthreads();                                     // every wave's stores of the stage are issued and drained
+    // every wave drains its own stores of the stage (the barrier's own wait is lgkmcnt only), THEN the workgroup
+    // meets, then one lane writes this XCD's L2 back (all of the workgroup's stores are in it by now) and arrives
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the compiler may drop the wait behind the write-back)
         __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int ok = 0;
-        for (unsigned spin = 0; spin < (1u << 21); spin++) {
+        for (unsigned spin = 0; spin < spin_cap; spin++) {
             if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) { ok = 1; break; }
             __builtin_amdgcn_s_sleep(8);
         }
@@ -1783,11 +1823,13 @@ __device__ __forceinline__ bool stage_barrier(unsigned* __restrict__ ctr, unsign
 __global__ __launch_bounds__(256, 2) void k_trtri_block(const double* __restrict__ L, const double* __restrict__ d64,
                                                         double* __restrict__ T, double* __restrict__ U, int ld, int a,
                                                         int wb, unsigned* __restrict__ ctr, double* __restrict__ poison,
-                                                        int ctr_off, const ExpertPtrs* __restrict__ bt)
+                                                        int ctr_off, unsigned spin_cap, double* __restrict__ hstat,
+                                                        const ExpertPtrs* __restrict__ bt)
 {
     if (bt) {
         const ExpertPtrs& e = bt[blockIdx.y];
         L = GP(e.A); d64 = GP(e.d64); T = GP(e.T); U = GP(e.U); ctr = GP(e.tickets) + ctr_off; poison = GP(e.logdet);
+        if (hstat) hstat += (size_t)blockIdx.y * 8;
     }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     WGT(wgt_, WGT_TRTRI_DIAG, a);
@@ -1804,14 +1846,19 @@ __global__ __launch_bounds__(256, 2) void k_trtri_block(const double* __restrict
     bool ok = true;
     for (int s = 1; s < wb; s *= 2)
         for (int step = 1; step <= 2; step++) {
-            ok = stage_barrier(ctr, (unsigned)G * ++stage) && ok;
+            ok = stage_barrier(ctr, (unsigned)G * ++stage, spin_cap) && ok;
             const int items = level_tiles(wb, s) * 4;
             for (int it = wg; it < items; it += G) {
                 if (it != wg) __syncthreads();           // (the transposed store of the item before still reads its LDS image)
                 level_item<2>(Lb, Tb, Ub, ld, wb, s, step, it >> 2, it & 3, smem);
             }
         }
-    if (!ok && threadIdx.x == 0) poison[a] = __builtin_nan("");
+    // a wait that ran out: this block's numbers are not to be trusted -- NaN into its log-determinant share (the
+    // evaluation's values come back NaN) and the handle's pinned status word (its fetch returns CUGP_ERR_DEVICE)
+    if (!ok && threadIdx.x == 0) {
+        poison[a] = __builtin_nan("");
+        if (hstat) hstat[6] = 1.0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2040,7 +2087,27 @@ __global__ __launch_bounds__(256) void k_predict_finish(const double* __restrict
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
-int g_tune[TUNE_COUNT] = {768, 1200, 384, -1, 511, 1, 1, 1 << 20, 16, 500, 32, 1, 1, 256, 1536, 0};   // defaults chosen by interleaved A/B runs (tools/ab.py)
+// Per-launch timing without extra packets on the stream (profiling level 4, cugp_capi.cpp TimedLaunch): the next launch
+// of a timed kernel on this thread goes out through hipExtLaunchKernelGGL with a start / stop event pair, which take
+// the dispatch's OWN begin / end timestamps -- what rocprofv3 --kernel-trace reports for it.  (An event pair recorded
+// around the launch, level 3, brackets the ~6 us between the record in front of it and its first workgroup as well
+// and costs ~5 us of device time per pair.)
+thread_local hipEvent_t t_ev0 = nullptr, t_ev1 = nullptr;
+void time_next_launch(hipEvent_t start, hipEvent_t stop) { t_ev0 = start; t_ev1 = stop; }
+bool timing_pending() { return t_ev0 != nullptr; }
+#define CUGP_LAUNCH(kernel, grid, block, lds, stream, ...)                                          \
+    do {                                                                                            \
+        if (t_ev0) {                                                                                \
+            hipEvent_t e0_ = t_ev0, e1_ = t_ev1;                                                    \
+            t_ev0 = t_ev1 = nullptr;                                                                \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, e0_, e1_, 0, __VA_ARGS__);      \
+        } else {                                                                                    \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                      \
+        }                                                                                           \
+    } while (0)
+
+const int g_tune_init[TUNE_COUNT] = {768, 1200, 384, -1, 511, 1, 1, 1 << 20, 16, 500, 32, 1, 1, 256, 1536, 0, 1 << 21, 0};   // defaults chosen by interleaved A/B runs (tools/ab.py)
+thread_local const int* t_tune = g_tune_init;
 
 static inline int tri_count(int n) { return n * (n + 1) / 2; }
 
@@ -2116,7 +2183,7 @@ void launch_trtri_diag(const double* A, int ld, int kb, int nblocks, const doubl
 }
 
 int launch_trtri_block(const double* L, const double* d64, double* T, double* U, int ld, int a, int wb, unsigned* ctr,
-                       double* poison, int ctr_off, hipStream_t s, Batch bt)
+                       double* poison, int ctr_off, hipStream_t s, Batch bt, int gcap, double* hstat)
 {
     if (wb <= 0) return 0;
     set_big_lds();
@@ -2126,8 +2193,9 @@ int launch_trtri_block(const double* L, const double* d64, double* T, double* U,
         if (items > G) G = items;
     }
     if (G > TRTRI_BLOCK_MAXWG) G = TRTRI_BLOCK_MAXWG;
-    hipLaunchKernelGGL(k_trtri_block, dim3(G, bt.count), dim3(256), TRTRI_BLOCK_LDS, s, L, d64, T, U, ld, a, wb, ctr,
-                       poison, ctr_off, bt.tab);
+    if (gcap >= 1 && G > gcap) G = gcap;                  // (every workgroup count gives the same bits: a stage's items are independent)
+    CUGP_LAUNCH(k_trtri_block, dim3(G, bt.count), dim3(256), TRTRI_BLOCK_LDS, s, L, d64, T, U, ld, a, wb, ctr,
+                       poison, ctr_off, (unsigned)tune(TUNE_BARRIER_SPIN), hstat, bt.tab);
     return G;
 }
 
@@ -2138,7 +2206,7 @@ static int split_round(int tiles, int count)
 {
     const int slots = 512 / (count > 0 ? count : 1) > 0 ? 512 / (count > 0 ? count : 1) : 1;
     const int rem = tiles % slots;
-    if (tiles < slots || rem == 0 || rem > g_tune[TUNE_SPLIT_REM_MAX]) return tiles;
+    if (tiles < slots || rem == 0 || rem > tune(TUNE_SPLIT_REM_MAX)) return tiles;
     return tiles - rem;
 }
 
@@ -2158,13 +2226,14 @@ void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* d6
     // would be less than three quarters full
     const int ntl = trap_count(m, wcol) - 1;
     int nfull = ntl;
-    if (ntl >= 512 && (ntl % 512) <= g_tune[TUNE_SYRK_REM_MAX]) nfull = ntl - ntl % 512;
+    if (ntl >= 512 && (ntl % 512) <= tune(TUNE_SYRK_REM_MAX)) nfull = ntl - ntl % 512;
     // Few tiles (the chain-bound tail of the factorisation): a 128x128 workgroup alone on its CU issues one MFMA
     // per ~138 cycles (one wave per SIMD: half the pipe's rate) and takes ~40 us -- as long as the diagonal block
     // inside this launch.  As 64x64 quarters the same tiles take ~12 us per round of 512 workgroups.
-    if ((long long)ntl * bt.count * 4 <= g_tune[TUNE_STEP_QUARTER_MAX]) nfull = 0;
+    if ((long long)ntl * bt.count * 4 <= tune(TUNE_STEP_QUARTER_MAX)) nfull = 0;
     const unsigned nwg = NDIAGWG + nfull + 4 * (ntl - nfull);
-    hipLaunchKernelGGL(k_syrk_step, bt.tab ? dim3(bt.count, nwg) : dim3(nwg), dim3(256), STEP_LDS, s, A, ld, kb, d16,
+    stream_c = (stream_c ? 1 : 0) | ((tune(TUNE_CHAIN) >> 7) & 6);     // (bits 0x100, 0x200: timing experiments)
+    CUGP_LAUNCH(k_syrk_step, bt.tab ? dim3(bt.count, nwg) : dim3(nwg), dim3(256), STEP_LDS, s, A, ld, kb, d16,
                        d64, logdet_part, tickets, nfull, wcol, stream_c, bt.tab);
 }
 
@@ -2176,7 +2245,7 @@ int launch_syrk_wide(double* A, int ld, int nt, int k0, int kw, int ca, int cb, 
     set_big_lds();
     const int ntiles = trap_count(nt - ca, cb - ca);
     const int nfull = split_round(ntiles, bt.count);
-    hipLaunchKernelGGL(k_syrk_wide, dim3(nfull + 4 * (ntiles - nfull), bt.count), dim3(256), GEMM_LDS, s, A, ld, k0, kw, ca,
+    CUGP_LAUNCH(k_syrk_wide, dim3(nfull + 4 * (ntiles - nfull), bt.count), dim3(256), GEMM_LDS, s, A, ld, k0, kw, ca,
                        cb, ntiles, nfull, rev, bt.tab);
     return ntiles;
 }
@@ -2194,12 +2263,12 @@ int launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, in
     if (tiles <= 0) return 0;
     // few 128-tiles cannot fill 512 workgroup slots: use 64x64 output tiles (4x the parallelism) there
     set_big_lds();
-    if (tiles * bt.count <= g_tune[TUNE_TRTRI_WM2_MAX]) {  // (a batched launch fills the chip with fewer tiles each)
-        hipLaunchKernelGGL(k_trtri_level<2>, dim3(tiles * 4, bt.count), dim3(256), Geo<2>::LDS, st, L, T, U, ld, nt, s,
+    if (tiles * bt.count <= tune(TUNE_TRTRI_WM2_MAX)) {  // (a batched launch fills the chip with fewer tiles each)
+        CUGP_LAUNCH(k_trtri_level<2>, dim3(tiles * 4, bt.count), dim3(256), Geo<2>::LDS, st, L, T, U, ld, nt, s,
                            step, off, bt.tab);
         return 2;
     }
-    hipLaunchKernelGGL(k_trtri_level<4>, dim3(tiles, bt.count), dim3(256), GEMM_LDS, st, L, T, U, ld, nt, s, step,
+    CUGP_LAUNCH(k_trtri_level<4>, dim3(tiles, bt.count), dim3(256), GEMM_LDS, st, L, T, U, ld, nt, s, step,
                        off, bt.tab);
     return 4;
 }
@@ -2212,13 +2281,13 @@ int launch_trtri_border1(const double* L, double* T, double* U, int ld, int ra, 
     const int tiles = c1 * rw;
     if (tiles <= 0) return 0;
     set_big_lds();
-    if (tiles * bt.count <= g_tune[TUNE_BORDER_WM2_MAX]) {
-        hipLaunchKernelGGL(k_trtri_border<2>, dim3(tiles * 4, bt.count), dim3(256), Geo<2>::LDS, st, L, T, U, ld, ra, rw,
+    if (tiles * bt.count <= tune(TUNE_BORDER_WM2_MAX)) {
+        CUGP_LAUNCH(k_trtri_border<2>, dim3(tiles * 4, bt.count), dim3(256), Geo<2>::LDS, st, L, T, U, ld, ra, rw,
                            1, c0, c1, 0, bt.tab);
         return 2;
     }
     const int nfull = split_round(tiles, bt.count);
-    hipLaunchKernelGGL(k_trtri_border<4>, dim3(nfull + 4 * (tiles - nfull), bt.count), dim3(256), GEMM_LDS, st, L, T,
+    CUGP_LAUNCH(k_trtri_border<4>, dim3(nfull + 4 * (tiles - nfull), bt.count), dim3(256), GEMM_LDS, st, L, T,
                        U, ld, ra, rw, 1, c0, c1, nfull, bt.tab);
     return 4;
 }
@@ -2229,13 +2298,13 @@ int launch_trtri_border2(const double* L, double* T, double* U, int ld, int a, i
     const int tiles = a * w;
     if (tiles <= 0) return 0;
     set_big_lds();
-    if (tiles * bt.count <= g_tune[TUNE_TRTRI_WM2_MAX]) {
-        hipLaunchKernelGGL(k_trtri_border<2>, dim3(tiles * 4, bt.count), dim3(256), Geo<2>::LDS, st, L, T, U, ld, a, w, 2,
+    if (tiles * bt.count <= tune(TUNE_TRTRI_WM2_MAX)) {
+        CUGP_LAUNCH(k_trtri_border<2>, dim3(tiles * 4, bt.count), dim3(256), Geo<2>::LDS, st, L, T, U, ld, a, w, 2,
                            0, 0, 0, bt.tab);
         return 2;
     }
     const int nfull = split_round(tiles, bt.count);
-    hipLaunchKernelGGL(k_trtri_border<4>, dim3(nfull + 4 * (tiles - nfull), bt.count), dim3(256), GEMM_LDS, st, L, T,
+    CUGP_LAUNCH(k_trtri_border<4>, dim3(nfull + 4 * (tiles - nfull), bt.count), dim3(256), GEMM_LDS, st, L, T,
                        U, ld, a, w, 2, 0, 0, nfull, bt.tab);
     return 4;
 }
@@ -2244,14 +2313,14 @@ int launch_lauum(const double* U, double* Kinv, int ld, int a, int w, hipStream_
 {
     set_big_lds();
     const int tiles = tri_count(a + w);
-    if (tiles * bt.count <= g_tune[TUNE_LAUUM_WM2_MAX]) {
-        hipLaunchKernelGGL(k_lauum<2>, dim3(tiles * 4, bt.count), dim3(256), Geo<2>::LDS, s, U, Kinv, ld, a, w, 0, bt.tab);
+    if (tiles * bt.count <= tune(TUNE_LAUUM_WM2_MAX)) {
+        CUGP_LAUNCH(k_lauum<2>, dim3(tiles * 4, bt.count), dim3(256), Geo<2>::LDS, s, U, Kinv, ld, a, w, 0, bt.tab);
         return 2;
     } else {
         // (a whole-matrix product, a = 0, has k ranges from 1 to a+w tiles, longest first: its tail is short tiles
         //  already; the split is for the block-wise calls, whose tiles all take w k tiles)
         const int nfull = a > 0 ? split_round(tiles, bt.count) : tiles;
-        hipLaunchKernelGGL(k_lauum<4>, dim3(nfull + 4 * (tiles - nfull), bt.count), dim3(256), GEMM_LDS, s, U, Kinv, ld,
+        CUGP_LAUNCH(k_lauum<4>, dim3(nfull + 4 * (tiles - nfull), bt.count), dim3(256), GEMM_LDS, s, U, Kinv, ld,
                            a, w, nfull, bt.tab);
         return 4;
     }
@@ -2260,7 +2329,7 @@ int launch_lauum(const double* U, double* Kinv, int ld, int a, int w, hipStream_
 void launch_predict_gemm(const double* Ks, const double* T, double* W, int ld, int ntt, int nt, hipStream_t s)
 {
     set_big_lds();
-    hipLaunchKernelGGL(k_predict_gemm, dim3(ntt * nt), dim3(256), GEMM_LDS, s, Ks, T, W, ld, ntt, nt);
+    CUGP_LAUNCH(k_predict_gemm, dim3(ntt * nt), dim3(256), GEMM_LDS, s, Ks, T, W, ld, ntt, nt);
 }
 
 void launch_predict_finish(const double* Ks, const double* W, const double* alpha, int n, int npad, int ntest,

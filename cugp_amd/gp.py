@@ -191,6 +191,16 @@ class Covsum:
         """Inverse blocks on further streams while the factorisation runs (default on; cugp_set_overlap)."""
         check(capi.lib().cugp_set_overlap(self._h, 1 if enable else 0))
 
+    def set_tuning(self, key, value, own=True):
+        """One launch-shape key (kernels.h TUNE_*) for THIS handle alone (cugp_set_handle_tuning); own=False hands the
+        key back to the process default (cugp_set_tuning)."""
+        check(capi.lib().cugp_set_handle_tuning(self._h, int(key), int(value), 1 if own else 0))
+
+    def get_tuning(self, key):
+        v = C.c_int()
+        check(capi.lib().cugp_get_handle_tuning(self._h, int(key), C.byref(v)))
+        return v.value
+
     def phase_ms(self):
         """Main-stream phases of the last evaluation.  With the overlap on, "potrf" includes the inverse blocks
         running beside it and "trtri" is what was left of them when the factorisation ended ("lauum" ~ 0)."""

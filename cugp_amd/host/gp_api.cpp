@@ -63,6 +63,9 @@ void setup(int n, int d)
         labels_host_buffers[b] = g_owned[4 + b] = new double[n];
     }
     must(cugp_create(n, d, 0, &g_gp), "setup");
+    // setup_input_datastructures resets lh_host to 0.5 on EVERY call (cuda_gp.cu:437-440): a second model set up in one
+    // process starts from the reference's initial hyper-parameters, not from what the previous model ended at
+    g_lh[0] = g_lh[1] = g_lh[2] = 0.5;
     must(cugp_set_loghyper(g_gp, g_lh), "cugp_set_loghyper");
 }
 

@@ -116,15 +116,19 @@ int cugp_potrs_vec(int n, const double *K, const double *y, double *x, int devic
  * cugp_get_kernel_stats: HIP-event time of every launch of the Cholesky trailing update (MFMA SYRK) in the
  * evaluations since the last reset: sum of durations (ms), launches, algorithmic flop */
 int cugp_set_profiling(cugp_gp *gp, int level /* 0 off, 1 phases, 2 phases + HIP events around a rotating sample of the
-                                                 MFMA kernels' launches, 3 phases + events around every such launch */);
+                                                 MFMA kernels' launches, 3 phases + events around every such launch,
+                                                 4 phases + every such launch timed by its OWN start / stop events
+                                                 (hipExtLaunchKernelGGL: the dispatch's begin / end as rocprofv3
+                                                 --kernel-trace reports them, no extra packets on the streams) */);
 int cugp_get_phase_ms(cugp_gp *gp, double ms[6]);
 int cugp_get_kernel_stats(cugp_gp *gp, double *sum_ms, long long *launches, double *flop, int reset);
 /* the same per kernel, as rocprofv3 names them: kind 0 = k_syrk_step (near-window update + next diagonal block,
  * K = 128; timed one launch in 16, rotating), 1 = k_syrk_wide (the far trailing matrix once per panel, K = 128 * panel
  * width), 2 / 3 = k_trtri_border<4> / <2> (bordering steps of L^-1) and 4 / 5 = k_lauum<4> / <2> (shares of K^-1):
  * timed for every fourth block of inverse rows, 6 / 7 = k_trtri_level<4> / <2> (doubling inside a block of rows; timed
- * one launch in 16), 8 = k_trtri_block (a hand-over block's own inverse in one launch; every fourth block).  The
- * sampling rates are those of level 2; level 3 times every launch.  flop = algorithmic
+ * one launch in 16), 8 = k_trtri_block (a hand-over block's own inverse in one launch; every fourth block), 9 =
+ * k_predict_gemm (W = Ks L^-T of cugp_predict; levels 3 and 4 only).  The
+ * sampling rates are those of level 2; levels 3 and 4 time every launch.  flop = algorithmic
  * (entries on or below the diagonal, a triangular k tile counted half), multiply + add */
 int cugp_get_kernel_stats_kind(cugp_gp *gp, int kind, double *sum_ms, long long *launches, double *flop, int reset);
 void *cugp_get_stream(cugp_gp *gp);          /* hipStream_t of the handle */
@@ -197,9 +201,15 @@ int cugp_mfma_peak_tflops(int device, double *tflops);
 int cugp_bench_la(int op, int n, int device, int reps, double *ms);
 /* the same, and for ops 0 and 3 log|K| taken from the factor the timed launches produced (NaN otherwise) */
 int cugp_bench_la_check(int op, int n, int device, int reps, double *ms, double *logdet);
-/* launch-shape thresholds (kernels.h TUNE_*), for A/B runs.  Process-wide and NOT thread-safe: call it only while no
- * other thread is inside the library (handles read the values while they enqueue). */
+/* launch-shape thresholds (kernels.h TUNE_*), for A/B runs.  cugp_set_tuning changes the PROCESS DEFAULT of a key
+ * (thread-safe: a lock); every handle carries its own copy and takes the defaults over when it next starts to enqueue,
+ * so an evaluation in flight keeps the shapes it was enqueued with.  cugp_set_handle_tuning sets a key for ONE handle
+ * (own != 0: later cugp_set_tuning calls no longer change it; own == 0: back to the default), called by the thread that
+ * owns the handle like every other call on it; cugp_get_handle_tuning reads the value the handle's next enqueue uses.
+ * (The reference has no counterpart: its launch shapes are compile-time constants, cuda_scalingdist/cuda_gp.cu:20-60.) */
 int cugp_set_tuning(int key, int value);
+int cugp_set_handle_tuning(cugp_gp *gp, int key, int value, int own);
+int cugp_get_handle_tuning(cugp_gp *gp, int key, int *value);
 /* the launches of step kb of the two-speed Cholesky with panels of P steps and a near window of about `near_tiles`
  * tiles (pure arithmetic, no device): out = {wide k0, wide k tiles, wide columns [a0,a1), step-launch width in tile
  * columns from kb+1}; tests/test_host_logic.py replays it: every tile sees every k exactly once, ascending */

@@ -1,0 +1,206 @@
+"""Guarantees about handles that used to live in tools/ only (round 5): many handles in flight together, every hand-over
+block size, the bounded stage barrier of k_trtri_block running out, per-handle tuning.  The reference is one GP per
+process (file-scope globals, cuda_scalingdist/main.cpp:14-67); the C-ABI promises thread-compatible handles
+(INTEGRATION.md, section E), and these tests hold it to that on the GPU."""
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import synth
+
+pytestmark = pytest.mark.gpu
+
+HP = np.array([np.log(3.0), 0.0, np.log(0.1)])
+TUNE_PIPE_BLOCK, TUNE_BARRIER_SPIN = 3, 16
+
+
+@pytest.fixture(scope="module")
+def gp_mod():
+    import cugp_amd.gp as gp
+    return gp
+
+
+def make(gp_mod, n, d, seed):
+    X, y = synth(n, d=d, seed=seed)
+    g = gp_mod.Covsum(n, d)
+    g.set_data(X, y)
+    return g
+
+
+def test_sixteen_handles_in_flight_equal_the_evaluations_alone(gp_mod):
+    """16 handles enqueue before the first fetch: every handle forks its inverse blocks to three further streams, so
+    dozens of k_trtri_block grids (stage barriers) are in flight beside hundreds of tile workgroups.  Every result must
+    be the bits of the same handle evaluated alone (tools/concurrent_handles.py, shrunk)."""
+    sizes = [1100, 1500, 900, 1300, 700, 1700, 515, 2100]
+    hs = [make(gp_mod, sizes[i % len(sizes)], 5, 100 + i) for i in range(16)]
+    alone = []
+    for g in hs:
+        g.set_loghyperparam(HP)
+        alone.append(g.loglik_grad())
+    for r in range(2):
+        for g in hs:
+            g.set_loghyperparam(HP + 1e-3 * (r + 1))
+            g.enqueue(True)
+        for g in hs:
+            g.fetch()
+        for g in hs:
+            g.set_loghyperparam(HP)
+            g.enqueue(True)
+        for i, g in enumerate(hs):
+            ll, gr = g.fetch()
+            assert ll == alone[i][0] and tuple(gr) == tuple(alone[i][1]), (i, ll, alone[i])
+    for g in hs:
+        g.close()
+
+
+def test_twelve_handles_with_whole_matrix_barrier_grids(gp_mod):
+    """The case the barrier budget exists for (cugp_capi.cpp: barrier_cap): overlap off, 9..16 tiles -- every handle's
+    whole inverse is ONE k_trtri_block launch that would like 64 co-resident workgroups; 12 of them in flight together
+    want 768 of the 512 workgroup slots.  With the budget each takes 384 / 12 = 32: nothing stalls, nothing times out,
+    and the bits are those of the handle alone (where the launch takes all 64: the workgroup count changes no result)."""
+    rows = [1153, 1300, 1500, 1700, 1900, 2048, 1200, 1400, 1600, 1800, 2000, 1250]      # 10..16 tiles
+    solo = make(gp_mod, rows[0], 4, 300)
+    solo.set_overlap(False)
+    solo.set_loghyperparam(HP)
+    first_alone = solo.loglik_grad()                     # one live handle: its launch holds 64 workgroups
+    solo.close()
+    hs = [make(gp_mod, n, 4, 300 + i) for i, n in enumerate(rows)]
+    for g in hs:
+        g.set_overlap(False)
+    for r in range(3):
+        for g in hs:
+            g.set_loghyperparam(HP + 1e-3 * r)
+            g.enqueue(True)
+        res = [g.fetch() for g in hs]                    # (a stage wait that ran out raises CUGP_ERR_DEVICE here)
+        assert all(np.isfinite(ll) and np.all(np.isfinite(gr)) for ll, gr in res)
+        if r == 0:
+            assert res[0][0] == first_alone[0] and tuple(res[0][1]) == tuple(first_alone[1])
+            again = []
+            for g in hs:                                 # one at a time, same budget share
+                g.set_loghyperparam(HP + 1.0)
+                g.loglik_grad()
+                g.set_loghyperparam(HP)
+                again.append(g.loglik_grad())
+            for a, b in zip(res, again):
+                assert a[0] == b[0] and tuple(a[1]) == tuple(b[1])
+    for g in hs:
+        g.close()
+
+
+def test_more_handles_than_the_barrier_budget_serves(gp_mod):
+    """Beyond 24 live handles on a device the block's own inverse goes launch by launch (k_trtri_diag + k_trtri_level:
+    nothing waits for anything).  Same tile code in the same order: the same bits as the one-launch form."""
+    g = make(gp_mod, 1500, 4, 77)
+    g.set_loghyperparam(HP)
+    one_launch = g.loglik_grad()
+    crowd = [gp_mod.Covsum(130, 4) for _ in range(25)]   # 26 live handles now
+    g.set_loghyperparam(HP + 1.0)
+    g.loglik_grad()
+    g.set_loghyperparam(HP)
+    by_launches = g.loglik_grad()
+    for c in crowd:
+        c.close()
+    assert one_launch[0] == by_launches[0] and tuple(one_launch[1]) == tuple(by_launches[1])
+    g.close()
+
+
+@pytest.mark.parametrize("n", [130, 515, 900, 1500, 2100, 2500])
+def test_every_hand_over_block_size(gp_mod, n):
+    """Hand-over blocks of 1..16 tiles (TUNE_PIPE_BLOCK, set for this handle only) against the single-stream evaluation
+    of the same handle: LL 1e-12, gradient 1e-9, K^-1 1e-11 of its largest entry (the partition changes summation
+    orders, nothing else) -- tools/block_sweep.py, shrunk."""
+    g = make(gp_mod, n, 7, n)
+    g.set_loghyperparam(HP)
+    g.set_overlap(False)
+    ll0, g0 = g.loglik_grad()
+    K0 = g.get_K_inverse()
+    g.set_overlap(True)
+    for w in (1, 2, 3, 4, 5, 7, 8, 11, 16):
+        g.set_tuning(TUNE_PIPE_BLOCK, w)
+        assert g.get_tuning(TUNE_PIPE_BLOCK) == w
+        g.set_loghyperparam(HP + 1e-9)
+        g.loglik_grad()
+        g.set_loghyperparam(HP)
+        ll, gr = g.loglik_grad()
+        Ki = g.get_K_inverse()
+        assert np.isfinite(ll) and abs(ll - ll0) <= 1e-12 * max(1.0, abs(ll0)), (w, ll, ll0)
+        assert np.max(np.abs(gr - g0) / (np.abs(g0) + 1e-9 * np.max(np.abs(g0)))) < 1e-9, (w, gr, g0)
+        assert np.max(np.abs(Ki - K0)) <= 1e-11 * np.max(np.abs(K0)), w
+    g.close()
+
+
+def test_a_stage_barrier_that_runs_out_is_an_error_not_a_hang(gp_mod):
+    """TUNE_BARRIER_SPIN = 0 on one handle: every workgroup of its k_trtri_block launches gives up at its first stage
+    barrier without waiting.  The evaluation must come back (no hung device) as CUGP_ERR_DEVICE, keep nothing (no
+    'valid' factor with a poisoned log-determinant share), and the next evaluation on the SAME handle -- spin bound
+    restored -- must be clean and equal to an untouched handle's.  A second handle is never affected."""
+    from cugp_amd import capi
+    n = 1500
+    g, other = make(gp_mod, n, 6, 5), make(gp_mod, n, 6, 5)
+    g.set_loghyperparam(HP)
+    other.set_loghyperparam(HP)
+    want = other.loglik_grad()
+    g.set_tuning(TUNE_BARRIER_SPIN, 0)
+    with pytest.raises(capi.CugpError) as ei:
+        g.loglik_grad()
+    assert ei.value.code == capi.CUGP_ERR_DEVICE and "barrier" in str(ei.value)
+    with pytest.raises(capi.CugpError):
+        g.last_quad_logdet()                              # nothing of the abandoned evaluation is "available"
+    assert other.get_tuning(TUNE_BARRIER_SPIN) == 1 << 21
+    ll_o, g_o = other.loglik_grad()
+    assert ll_o == want[0]
+    g.set_tuning(TUNE_BARRIER_SPIN, 0, own=False)        # back to the process default
+    assert g.get_tuning(TUNE_BARRIER_SPIN) == 1 << 21
+    ll, gr = g.loglik_grad()
+    assert ll == want[0] and tuple(gr) == tuple(want[1])
+    # the single-stream continuation (cugp_loglik, then the gradient from the valid factor) goes through the same launch
+    g.set_loghyperparam(HP + 0.25)
+    g.compute_loglikelihood()
+    g.set_tuning(TUNE_BARRIER_SPIN, 0)
+    with pytest.raises(capi.CugpError):
+        g.compute_gradient_loghyperparam()
+    g.set_tuning(TUNE_BARRIER_SPIN, 0, own=False)
+    other.set_loghyperparam(HP + 0.25)
+    want2 = other.loglik_grad()
+    ll2, gr2 = g.loglik_grad()                            # from the covariance build again
+    assert abs(ll2 - want2[0]) <= 1e-12 * abs(want2[0]) and np.allclose(gr2, want2[1], rtol=1e-9)
+    g.close()
+    other.close()
+
+
+def test_handle_tuning_from_two_threads(gp_mod):
+    """Two threads, one handle each, different hand-over block sizes set per handle while the other thread evaluates: each
+    handle's results equal its own single-threaded results at that setting (cugp_set_tuning was a shared mutable global
+    until round 5)."""
+    n = 1300
+    hs = [make(gp_mod, n, 5, 11), make(gp_mod, n, 5, 11)]
+    ws = [1, 3]
+    want = []
+    for g, w in zip(hs, ws):
+        g.set_tuning(TUNE_PIPE_BLOCK, w)
+        g.set_loghyperparam(HP)
+        want.append(g.loglik_grad())
+    errs = []
+
+    def run(i):
+        try:
+            g = hs[i]
+            for r in range(12):
+                g.set_tuning(TUNE_PIPE_BLOCK, ws[i])
+                g.set_loghyperparam(HP + 1e-3)
+                g.loglik_grad()
+                g.set_loghyperparam(HP)
+                ll, gr = g.loglik_grad()
+                assert ll == want[i][0] and tuple(gr) == tuple(want[i][1]), (i, r)
+        except Exception as e:                           # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for g in hs:
+        g.close()
