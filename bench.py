@@ -15,10 +15,11 @@ and the per-evaluation exchange is one all-reduce of K x 4 doubles over RCCL.
 
 The run is made of passes (--passes, default all three, in this order):
   timed      W warm-up + K evaluations on the DEFAULT path (no per-launch events, no instrumentation): `value`
-  profiled   the same K evaluations with every launch of every MFMA kernel timed by its OWN start / stop events
-             (cugp_set_profiling 4: hipExtLaunchKernelGGL, the dispatch's begin / end as rocprofv3 --kernel-trace
-             reports them, no extra packets on the streams): the `roofline*` records -- same schedule, the inverse
-             blocks beside the factorisation, so a launch shares the CUs with kernels on the other streams
+  profiled   the same K evaluations with every launch of every MFMA kernel (and the covariance build) timed by its own
+             workgroups (cugp_set_profiling 5: first workgroup's start / last workgroup's end on the chip-wide 100 MHz
+             clock, stamped into a device buffer; no events, nothing added to the streams): the `roofline*` records --
+             the timed pass's schedule, the inverse blocks beside the factorisation, so a launch shares the CUs with
+             kernels on the other streams
   isolated   8 evaluations with the overlap off (every kernel has the chip to itself): `isolated_*`, cholesky_gflops
 tools/make_profiles.sh runs rocprofv3 --kernel-trace --stats once per pass (--passes timed | profiled | isolated), so
 the average duration of a kernel in the CSV named in roofline.dominant_by reproduces roofline.achieved.
@@ -127,9 +128,12 @@ def main():
                     "and no extra pass is made)")
     ap.add_argument("--passes", default="timed,profiled,isolated", help="comma list of timed, profiled, isolated (see the "
                     "module docstring); the contract line needs `timed`")
-    ap.add_argument("--prof-level", type=int, default=4, help="profiling level of the profiled / isolated passes: 4 = every "
-                    "MFMA launch carries its own start / stop events (hipExtLaunchKernelGGL), 3 = an event pair recorded "
-                    "around every such launch (rounds 3-4: ~6 us of dispatch gap inside the bracket, ~5 us of device time per pair)")
+    ap.add_argument("--prof-level", type=int, default=5, help="profiling level of the profiled / isolated passes: 5 = every "
+                    "timed launch's own workgroups stamp their first start / last end (s_memrealtime) into a device buffer -- "
+                    "nothing is added to the streams, the schedule is the timed pass's; 4 = every MFMA launch carries its own "
+                    "start / stop events (hipExtLaunchKernelGGL: +3 %% per evaluation, the start event still sits in front of "
+                    "the dispatch gap); 3 = an event pair recorded around every such launch (rounds 3-4: ~6 us of dispatch gap "
+                    "inside the bracket, ~5 us of device time per pair)")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
@@ -214,7 +218,7 @@ def main():
         return float(tm_.item()), r_[0], r_[1]
 
     first = next(iter(bcm.local.values()), None)      # None: a rank that owns no expert
-    empty = {"launches": 0, "sum_ms": 0.0, "flop": 0.0}
+    empty = {"launches": 0, "sum_ms": 0.0, "flop": 0.0, "disp_ms": 0.0}
     nanph = {"potrf": float("nan"), "kbuild": float("nan")}
 
     # ---- pass 1, timed: the default path, nothing instrumented -> `value`
@@ -225,6 +229,7 @@ def main():
     # ---- pass 2, profiled: the same evaluations with HIP events around the MFMA launches -> roofline*
     timed_launches = can_profile and "profiled" in passes
     kst = {kd: dict(empty) for kd in KINDS}
+    kb_st = None
     ph = dict(nanph)
     dt_prof = None
     if timed_launches:
@@ -234,6 +239,7 @@ def main():
             first.kernel_stats(reset=True, kind=kd)
         dt_prof, ll_p, g_p = timed_steps(0, args.steps)
         kst = {kd: first.kernel_stats(kind=kd) for kd in KINDS}
+        kb_st = first.kernel_stats(kind=10) if args.prof_level >= 5 else None
         ph = first.phase_ms()
         if "timed" not in passes:
             dt, ll, g = dt_prof, ll_p, g_p
@@ -377,22 +383,28 @@ def main():
         except Exception:
             pmc = {}
 
+        def dur(st):
+            # level 5: from the end of the launch in front of it on its stream (where rocprofv3 puts an in-order
+            # dispatch's begin) to the launch's last workgroup; other levels: the event pair's bracket
+            return st["disp_ms"] if st.get("disp_ms", 0.0) > 0.0 else st["sum_ms"]
+
         def roof(kd, st, iso_st):
             name, what, every = KINDS[kd]
-            ach = st["flop"] / (st["sum_ms"] * 1e-3) / 1e12
+            ach = st["flop"] / (dur(st) * 1e-3) / 1e12
             r = {"kernel": "%s (%s; fp64 MFMA 16x16x4)" % (name, what), "bound": "mfma", "achieved": ach,
                  "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F64_PEAK_TFLOPS,
                  "traffic": pmc.get(name, {}).get("hbm_bytes_per_launch"),
                  "traffic_source": PMC_SUMMARY if name in pmc else None,
                  "mfma_busy_frac_pmc": pmc.get(name, {}).get("mfma_busy_frac"),
                  "launches_timed": int(st["launches"]), "timed_one_launch_in": 1,
-                 "avg_launch_us": 1e3 * st["sum_ms"] / st["launches"],
+                 "avg_launch_us": 1e3 * dur(st) / st["launches"],
+                 "avg_first_to_last_workgroup_us": 1e3 * st["sum_ms"] / st["launches"],
                  "algorithmic_flop_per_launch": st["flop"] / st["launches"],
-                 "est_ms_per_eval": st["sum_ms"] / args.steps}
+                 "est_ms_per_eval": dur(st) / args.steps}
             if iso_st and iso_st["launches"] > 0:
-                ia = iso_st["flop"] / (iso_st["sum_ms"] * 1e-3) / 1e12
+                ia = iso_st["flop"] / (dur(iso_st) * 1e-3) / 1e12
                 r.update({"isolated_achieved": ia, "isolated_frac": ia / MFMA_F64_PEAK_TFLOPS,
-                          "isolated_avg_launch_us": 1e3 * iso_st["sum_ms"] / iso_st["launches"]})
+                          "isolated_avg_launch_us": 1e3 * dur(iso_st) / iso_st["launches"]})
             return r
 
         recs = {KINDS[kd][0]: roof(kd, kst[kd], iso[kd] if iso else None) for kd in KINDS if kst[kd]["launches"] > 0}
@@ -408,9 +420,10 @@ def main():
                                               "of the timed pass: profiles/%s_bench_timed_n8192_kernel_stats.csv, of the "
                                               "isolated pass: profiles/%s_bench_isolated_n8192_kernel_stats.csv"
                                               % (ROUND, ROUND, ROUND))
-            out["roofline"]["note"] = ("achieved/frac: profiled pass = the timed pass's schedule with every launch timed by "
-                                       "its own start/stop events (level %d), where a launch shares the CUs with kernels "
-                                       "on the other streams; isolated_*: same kernel, overlap off" % args.prof_level)
+            out["roofline"]["note"] = ("achieved/frac: profiled pass = the timed pass's schedule with every launch timed "
+                                       "(profiling level %d: 5 = by its own workgroups' first start / last end, nothing added "
+                                       "to the streams), where a launch shares the CUs with kernels on the other streams; "
+                                       "isolated_*: same kernel, overlap off" % args.prof_level)
             out["roofline"]["whole_evaluation_frac"] = out["eval_tflops_n3"] / MFMA_F64_PEAK_TFLOPS
             out["roofline_kernels"] = recs
             ks, kw = kst[0], kst[1]
@@ -418,24 +431,27 @@ def main():
                 # the two kernels of the factorisation's trailing update together: their flop over the sum of their
                 # durations (profiled pass: every launch of both is timed)
                 fl = kw["flop"] + ks["flop"]
-                ms = kw["sum_ms"] + ks["sum_ms"]
+                ms = dur(kw) + dur(ks)
                 tu = {"what": "k_syrk_wide + k_syrk_step together (N^3/3 flop of the factorisation)",
                       "achieved": fl / (ms * 1e-3) / 1e12, "unit": "TFLOP/s", "peak": MFMA_F64_PEAK_TFLOPS,
                       "wide_share_of_flop": kw["flop"] / fl}
                 tu["frac"] = tu["achieved"] / MFMA_F64_PEAK_TFLOPS
                 if iso and iso[0]["launches"] > 0 and iso[1]["launches"] > 0:
-                    ia = (iso[1]["flop"] + iso[0]["flop"]) / ((iso[1]["sum_ms"] + iso[0]["sum_ms"]) * 1e-3) / 1e12
+                    ia = (iso[1]["flop"] + iso[0]["flop"]) / ((dur(iso[1]) + dur(iso[0])) * 1e-3) / 1e12
                     tu["isolated_achieved"], tu["isolated_frac"] = ia, ia / MFMA_F64_PEAK_TFLOPS
                 out["roofline_trailing_update"] = tu
         if timed_launches and ph["kbuild"] == ph["kbuild"]:
             # SE-kernel build: lower 64x64 tiles of K written once (+ X read), HIP events around its launch
             nbytes = (npad // 64) * (npad // 64 + 1) // 2 * 64 * 64 * 8 + args.n * args.d * 8
-            gbs = nbytes / (ph["kbuild"] * 1e-3) / 1e9
+            kb_ms = ph["kbuild"]                      # phase events around the launch (levels < 5) ...
+            if kb_st and kb_st["launches"] > 0:       # ... or the launch's own workgroup stamps, averaged over the pass
+                kb_ms = kb_st["sum_ms"] / kb_st["launches"]
+            gbs = nbytes / (kb_ms * 1e-3) / 1e9
             out["roofline_kbuild"] = {"kernel": "k_build (SE covariance, lower tiles)", "bound": "hbm", "achieved": gbs,
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                       "traffic": pmc.get("k_build", {}).get("hbm_bytes_per_launch"),
                                       "traffic_source": PMC_SUMMARY if "k_build" in pmc else None,
-                                      "launch_us": 1e3 * ph["kbuild"], "algorithmic_bytes": nbytes,
+                                      "launch_us": 1e3 * kb_ms, "algorithmic_bytes": nbytes,
                                       "note": "bound in practice by N^2/2 fp64 exp evaluations, not by HBM"}
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, args.n), args.n, args.d)

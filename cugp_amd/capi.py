@@ -66,6 +66,7 @@ SIGNATURES = {
     "cugp_get_phase_ms": (C.c_int, [C.c_void_p, _dp]),
     "cugp_get_kernel_stats": (C.c_int, [C.c_void_p, _dp, C.POINTER(C.c_longlong), _dp, C.c_int]),
     "cugp_get_kernel_stats_kind": (C.c_int, [C.c_void_p, C.c_int, _dp, C.POINTER(C.c_longlong), _dp, C.c_int]),
+    "cugp_get_kernel_stats_dispatch_ms": (C.c_int, [C.c_void_p, C.c_int, _dp]),
     "cugp_get_stream": (C.c_void_p, [C.c_void_p]),
     "cugp_cg_minimize": (C.c_int, [OBJECTIVE, C.c_void_p, _dp, C.c_int, _dp, C.c_int, _ip]),
     "cugp_rprop_minimize": (C.c_int, [OBJECTIVE, C.c_void_p, _dp, C.c_int, _dp, C.c_int, _ip]),

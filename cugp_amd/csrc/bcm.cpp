@@ -73,7 +73,11 @@ int cugp_bcm_create_multi(int ndev, const int* devices, int nexperts, const int*
         ds.idx.push_back(k);
     }
     for (DeviceSet& ds : b->sets) {
-        if (ds.idx.size() < 2) continue;
+        // A set of ONE expert beside larger sets (5 experts over 3 devices: 2 + 2 + 1) is a group of one: it then takes
+        // its inverse in the same hand-over blocks as the other sets' groups.  Since round 5 an accumulate-form tile
+        // product adds its C tile in the epilogue, so the bits of K^-1 depend on where the block boundaries are; with
+        // its overlap off (below: nexperts > nsets) the lone expert would take the whole-matrix form instead.
+        if (ds.idx.size() < 2 && !(nexperts > nsets)) continue;
         std::vector<cugp_gp*> mine;
         for (int k : ds.idx) mine.push_back(b->experts[k]);
         if (cugp_group_create(mine.data(), (int)mine.size(), &ds.group) != CUGP_OK) ds.group = nullptr;

@@ -49,12 +49,13 @@ int fail(int code, const char* what, hipError_t e = hipSuccess)
 
 constexpr int NPHASE = 6;
 constexpr int MAX_KEV = 4096;   // per-launch event pairs kept between resets
+static_assert(MAX_KEV / 2 == cugp::STAMP_STRIDE, "one stamp slot per timed launch");
 constexpr int GRAPH_MAX_TILES = 24;   // evaluations up to 3072 rows are replayed as captured graphs
 constexpr int PROF_STRIDE = 16; // profiling level 2 times every 16th step launch, rotating (an event pair costs ~5 us of device time);
                                 // level 3 times EVERY launch of the MFMA kernels (bench.py's profiled pass: averages comparable with rocprofv3's)
 // kinds of timed launches (cugp_get_kernel_stats_kind): the kernels as rocprofv3 names them
 enum { KIND_STEP = 0, KIND_WIDE = 1, KIND_BORDER4 = 2, KIND_BORDER2 = 3, KIND_LAUUM4 = 4, KIND_LAUUM2 = 5,
-       KIND_LEVEL4 = 6, KIND_LEVEL2 = 7, KIND_BLOCK = 8, KIND_PREDICT = 9, KIND_COUNT = 10 };
+       KIND_LEVEL4 = 6, KIND_LEVEL2 = 7, KIND_BLOCK = 8, KIND_PREDICT = 9, KIND_BUILD = 10, KIND_TRSM = 11, KIND_COUNT = 12 };
 
 // One hardware queue per stream up to 16 (the runtime default is 4): the experts of a BCM on one device each
 // drive their own stream, and 16 experts on 4 queues serialise (5.8 ms vs 4.6 ms per evaluation of 16 x 1500
@@ -122,9 +123,15 @@ struct cugp_gp {
     std::vector<int> kev_kind;     // per pair: KIND_* below
     std::vector<double> kev_flopv; // per pair: algorithmic flop of the launch
     int kev_used = 0;
+    unsigned long long* dstamps = nullptr;   // level 5: [0, STAMP_STRIDE) first-workgroup starts, [STAMP_STRIDE, 2 STAMP_STRIDE) last-workgroup ends
+    std::vector<unsigned long long> hstamps;
     unsigned eval_seq = 0;         // factorisations enqueued so far (rotates the launches that get timed)
     double kst_ms[KIND_COUNT] = {}, kst_flop[KIND_COUNT] = {};   // folded sums per kernel kind
+    double kst_disp_ms[KIND_COUNT] = {};   // level 5: the same launches from the END of the launch in front of them on their stream
+                                           // (= where rocprofv3 puts a back-to-back dispatch's begin) to their own end
     long long kst_launches[KIND_COUNT] = {};
+    std::vector<int> kev_prev;     // level 5, per pair: the pair of the launch directly in front of it on the same stream, or -1
+    int last_main = -1;            // ... the main stream's latest timed launch while the factorisation is being enqueued
 };
 
 namespace {
@@ -165,9 +172,26 @@ int ensure_inverse_bufs(cugp_gp* g)
 
 void drain_kernel_events(cugp_gp* g)
 {
-    // fold finished per-launch events into the running sums (events are on g->stream, already synchronised)
+    // fold finished per-launch timings into the running sums (everything is on or joined to g->stream, already synchronised)
+    const bool stamps = g->prof >= 5 && g->dstamps && g->kev_used > 0;
+    if (stamps && hipMemcpy(g->hstamps.data(), g->dstamps, (size_t)2 * STAMP_STRIDE * sizeof(unsigned long long),
+                            hipMemcpyDeviceToHost) != hipSuccess) { g->kev_used = 0; return; }
     for (int i = 0; i + 1 < g->kev_used; i += 2) {
         float ms = 0;
+        if (stamps) {
+            const unsigned long long t0 = g->hstamps[i / 2], t1 = g->hstamps[STAMP_STRIDE + i / 2];
+            if (t1 <= t0) continue;                              // (the launch never ran)
+            const int kd = g->kev_kind[i / 2];
+            g->kst_ms[kd] += (double)(t1 - t0) * 1e-5;           // 100 MHz ticks -> ms
+            g->kst_launches[kd] += 1;
+            g->kst_flop[kd] += g->kev_flopv[i / 2];
+            // dispatch begin .. end as rocprofv3 sees an in-order launch behind another: from the end of the launch in
+            // front of it (its workgroups may then still wait for slots held by the other streams' tiles)
+            const int pv = g->kev_prev[i / 2];
+            const unsigned long long pe = pv >= 0 ? g->hstamps[STAMP_STRIDE + pv] : 0ull;
+            g->kst_disp_ms[kd] += (double)(t1 - ((pe > 0 && pe < t1 && pe <= t0) ? pe : t0)) * 1e-5;
+            continue;
+        }
         if (hipEventElapsedTime(&ms, g->kev[i], g->kev[i + 1]) == hipSuccess) {
             const int kd = g->kev_kind[i / 2];
             g->kst_ms[kd] += ms;
@@ -254,16 +278,21 @@ int pipe_block(const cugp_gp* g, bool with_inverse)
 // one timed launch: event pair + bookkeeping.  Levels 2 and 3 record an event in front of and behind the launch on its
 // stream; level 4 hands the pair to the launch itself (hipExtLaunchKernelGGL: the dispatch's own begin / end, no extra
 // packets on the stream -- the schedule of the timed pass, and the durations rocprofv3 --kernel-trace reports)
+// level 5: no events at all -- the launch's own workgroups stamp a slot of g->dstamps (kernels.hip LaunchStamp)
 struct TimedLaunch {
     cugp_gp* g; hipStream_t s; bool on, ext;
-    TimedLaunch(cugp_gp* g_, hipStream_t s_, bool want)
+    // chain: this launch goes out on the main stream directly behind the main stream's latest timed launch
+    TimedLaunch(cugp_gp* g_, hipStream_t s_, bool want, bool chain = false)
         : g(g_), s(s_), on(want && g_->kev_used + 2 <= (int)g_->kev.size()), ext(g_->prof >= 4)
     {
-        if (!on) return;
-        if (ext) time_next_launch(g->kev[g->kev_used], g->kev[g->kev_used + 1]);
+        if (!on) { if (chain) g->last_main = -1; return; }       // an untimed launch breaks the chain
+        g->kev_prev[g->kev_used / 2] = chain ? g->last_main : -1;
+        if (chain) g->last_main = g->kev_used / 2;
+        if (g->prof >= 5) stamp_next_launch(g->dstamps + g->kev_used / 2);
+        else if (ext) time_next_launch(g->kev[g->kev_used], g->kev[g->kev_used + 1]);
         else if (hipEventRecord(g->kev[g->kev_used], s) != hipSuccess) on = false;
     }
-    ~TimedLaunch() { if (on && ext && timing_pending()) time_next_launch(nullptr, nullptr); }   // the launch did not happen
+    ~TimedLaunch() { if (on && ext && timing_pending()) { time_next_launch(nullptr, nullptr); stamp_next_launch(nullptr); } }   // the launch did not happen
     void done(int kind, double flop)
     {
         if (!on) return;
@@ -461,6 +490,16 @@ int enqueue_last_block(cugp_gp* g, int a, int idx)
 int phase_mark(cugp_gp* g, int i);
 int fetch_eval(cugp_gp* g);
 
+// level 5: the slots the timed launches enqueued from here on stamp (the sums of the ones before were drained by the
+// fetch that synchronised them): starts to ~0, ends to 0, on the handle's stream in front of those launches
+int reset_stamps(cugp_gp* g)
+{
+    if (g->prof < 5 || !g->dstamps) return CUGP_OK;
+    HIPCHK(hipMemsetAsync(g->dstamps, 0xff, (size_t)STAMP_STRIDE * sizeof(unsigned long long), g->stream));
+    HIPCHK(hipMemsetAsync(g->dstamps + STAMP_STRIDE, 0, (size_t)STAMP_STRIDE * sizeof(unsigned long long), g->stream));
+    return CUGP_OK;
+}
+
 
 // The shares of K^-1 on a stream of their own (beside the next block's bordering) or behind their block's bordering:
 // for a group of experts two large launches in flight fill each other's partly empty last rounds (-3...-6 % per
@@ -598,8 +637,14 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false, const unsign
     else if (g->grp) HIPCHK(hipMemsetAsync(g->grp->tickets, 0, (size_t)g->grp->bt.count * 2 * nt * sizeof(unsigned), m));
     else HIPCHK(hipMemsetAsync(g->dtickets, 0, (size_t)2 * nt * sizeof(unsigned), m));
     launch_potf2(g->dA, ld, 0, g->d16, g->d64, g->dlogdet, m, B(g));
+    g->last_main = -1;
+    const bool l5 = g->prof >= 5;                           // level 5: every launch of the factorisation's stream is stamped
     for (int kb = 0; kb + 1 < nt; kb++) {
-        launch_trsm_inv64(g->dA, g->d64, ld, kb, nt, m, B(g));
+        {
+            TimedLaunch tl(g, m, l5, true);
+            launch_trsm_inv64(g->dA, g->d64, ld, kb, nt, m, B(g));
+            tl.done(KIND_TRSM, 2.0 * (nt - kb - 1) * TILE * (double)TILE * TILE / 2);      // (triangular solve: half a product)
+        }
         // block rows < kb+1 of L are final, and so are the columns <= kb of every row below them
         const int b = kb + 1;
         const bool hand_over = w > 0 && b - done >= w;
@@ -608,13 +653,13 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false, const unsign
         if (sp.wa1 > sp.wa0) {
             // panel p is factored (its last panel solve is enqueued): the far columns get the panel's K = P*128 in
             // one pass, before the next panel's first step widens the near window into them
-            TimedLaunch tl(g, m, g->prof >= 2);
+            TimedLaunch tl(g, m, g->prof >= 2, true);
             launch_syrk_wide(g->dA, ld, nt, sp.wide_k0, sp.wide_kw, sp.wa0, sp.wa1, (kb / P) & 1, m, B(g));
             tl.done(KIND_WIDE, trailing_flop(nt, sp.wa0, sp.wa1, sp.wide_kw));
         }
         // level 2 times a rotating eighth of the step launches (every step is sampled once in 8 evaluations):
         // an event pair around every launch costs several percent of the evaluation
-        TimedLaunch tl(g, m, sampled(g, kb + (int)g->eval_seq, PROF_STRIDE));
+        TimedLaunch tl(g, m, sampled(g, kb + (int)g->eval_seq, PROF_STRIDE), true);
         // (look-ahead form: plain stores -- the panel solve that follows reads the column at once, and reading
         //  freshly non-temporally stored tiles took it 50 us instead of 16)
         launch_syrk_step(g->dA, ld, kb, nt, g->d16, g->d64, g->dlogdet, g->dtickets, m, B(g), sp.wcol,
@@ -674,7 +719,13 @@ int record_eval(cugp_gp* g, bool want_grad, const HyperScalars* hd)
     if (hd) HIPCHK(hipMemcpyAsync(g->dhs, g->hhs, sizeof(HyperScalars), hipMemcpyHostToDevice, s));
     if ((rc = phase_mark(g, 0))) return rc;
     unsigned* const tickets = g->grp ? g->grp->tickets : g->dtickets;
-    launch_kbuild(g->dX, g->n, g->d, g->npad, h, g->dA, false, s, hd, B(g), tickets);   // also zeroes the step tickets
+    if ((rc = reset_stamps(g))) return rc;
+    {
+        TimedLaunch tl(g, s, g->prof >= 5);
+        launch_kbuild(g->dX, g->n, g->d, g->npad, h, g->dA, false, s, hd, B(g), tickets);   // also zeroes the step tickets
+        // (bytes, not flop: the lower 64x64 tiles of K written once + X read)
+        tl.done(KIND_BUILD, (double)trace_num_blocks(g->npad) * 64 * 64 * 8 + (double)g->n * g->d * 8);
+    }
     if ((rc = phase_mark(g, 1))) return rc;
     g->vec_early = want_grad;
     g->vec_done = false;
@@ -770,6 +821,7 @@ int enqueue_continue(cugp_gp* g)
     hipStream_t s = g->stream;
     g->inverse_valid = false;
     HIPCHK(hipMemsetAsync(g->dtickets + g->nt, 0, (size_t)g->nt * sizeof(unsigned), s));     // k_trtri_block's stage counters
+    if ((rc = reset_stamps(g))) return rc;
     if ((rc = enqueue_inverse_block(g, 0, g->nt, true, s, nullptr, nullptr))) return rc;
     launch_trmv_lower(g->dT, g->npad, g->npad, g->dy, g->dz, s);
     launch_trmv_upper(g->dU, g->npad, g->npad, g->dz, g->dalpha, s);
@@ -911,6 +963,7 @@ int cugp_destroy(cugp_gp* g)
     for (double* p : bufs)
         if (p) (void)hipFree(p);
     if (g->dtickets) (void)hipFree(g->dtickets);
+    if (g->dstamps) (void)hipFree(g->dstamps);
     if (g->pred_buf) (void)hipFree(g->pred_buf);
     if (g->hout) (void)hipHostFree(g->hout);
     if (g->hhs) (void)hipHostFree(g->hhs);
@@ -1082,6 +1135,7 @@ static int predict_device(cugp_gp* g, const double* Xt, int nt, double** dmean_o
     double* dm = dW + nks;
     double* dv = dm + nv;
     HIPCHK(hipMemcpyAsync(dXt, Xt, (size_t)nt * g->d * sizeof(double), hipMemcpyHostToDevice, g->stream));
+    if ((rc = reset_stamps(g))) return rc;
     launch_kcross(g->dX, g->n, g->d, g->npad, dXt, nt, ntpad, h, dKs, g->stream);
     {
         // W = Ks L^-T: test tile tt, row tile ti sums k <= ti (the diagonal k tile of T is triangular: counted half)
@@ -1325,8 +1379,13 @@ int cugp_set_profiling(cugp_gp* g, int level)
     if (level >= 2 && g->kev.empty()) {
         g->kev.resize(MAX_KEV);
         g->kev_kind.assign(MAX_KEV / 2, 0);
+        g->kev_prev.assign(MAX_KEV / 2, -1);
         g->kev_flopv.assign(MAX_KEV / 2, 0.0);
         for (auto& e : g->kev) HIPCHK(hipEventCreate(&e));
+    }
+    if (level >= 5 && !g->dstamps) {
+        HIPCHK(hipMalloc((void**)&g->dstamps, (size_t)2 * STAMP_STRIDE * sizeof(unsigned long long)));
+        g->hstamps.assign((size_t)2 * STAMP_STRIDE, 0ull);
     }
     return CUGP_OK;
 }
@@ -1357,7 +1416,20 @@ int cugp_get_kernel_stats_kind(cugp_gp* g, int kind, double* sum_ms, long long* 
     if (sum_ms) *sum_ms = g->kst_ms[kind];
     if (launches) *launches = g->kst_launches[kind];
     if (flop) *flop = g->kst_flop[kind];
-    if (reset) { g->kst_ms[kind] = 0; g->kst_launches[kind] = 0; g->kst_flop[kind] = 0; }
+    if (reset) { g->kst_ms[kind] = 0; g->kst_launches[kind] = 0; g->kst_flop[kind] = 0; g->kst_disp_ms[kind] = 0; }
+    return CUGP_OK;
+}
+
+// level 5 only: the same launches' durations counted from the END of the launch directly in front of each on its
+// stream (the chain of the factorisation's stream: panel solve -> [far update] -> step launch -> ...), which is where
+// rocprofv3 --kernel-trace puts the begin of an in-order dispatch behind another; launches without such a
+// predecessor count from their first workgroup's start.  Read it BEFORE a resetting cugp_get_kernel_stats_kind.
+int cugp_get_kernel_stats_dispatch_ms(cugp_gp* g, int kind, double* sum_ms)
+{
+    if (!g || !sum_ms || kind < 0 || kind >= KIND_COUNT) return CUGP_ERR_INVALID;
+    int rc;
+    if ((rc = fetch_eval(g))) return rc;
+    *sum_ms = g->kst_disp_ms[kind];
     return CUGP_OK;
 }
 

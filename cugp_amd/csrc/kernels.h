@@ -133,6 +133,11 @@ void launch_finalize(const double* z, int npad, int n, const double* logdet_part
 // profiling level 4: the NEXT launch of a timed kernel (trailing updates, inverse products, k_trtri_block,
 // k_predict_gemm) on this thread carries these events as the dispatch's own start / stop (hipExtLaunchKernelGGL)
 void time_next_launch(hipEvent_t start, hipEvent_t stop);
+// profiling level 5: the next launch of a timed kernel (the same set, and k_build) on this thread leaves its first
+// workgroup's start in slot[0] and its last workgroup's end in slot[STAMP_STRIDE] (s_memrealtime, 100 MHz ticks); the
+// caller has set slot[0] = ~0 and slot[STAMP_STRIDE] = 0
+constexpr int STAMP_STRIDE = 2048;
+void stamp_next_launch(unsigned long long* slot);
 bool timing_pending();   // still armed: the launch it was meant for did not happen
 // per-device function attributes (dynamic LDS sizes) for the current device; the launchers do it lazily, a
 // stream capture must not.  Returns the hipError_t of a failed hipFuncSetAttribute (0 = fine).

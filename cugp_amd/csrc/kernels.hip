@@ -86,6 +86,30 @@ unsigned wgt_fetch(unsigned long long* out, unsigned cap)
 enum { WGT_TRSM = 0, WGT_DIAGUPD = 1, WGT_POTF2 = 2, WGT_STEPTILE = 3, WGT_BORDER = 4, WGT_LAUUM = 5, WGT_LEVEL = 6,
        WGT_TRTRI_DIAG = 7, WGT_WIDE = 8 };
 
+// Profiling level 5 (cugp_capi.cpp TimedLaunch): a timed launch carries a slot in a device buffer and every workgroup
+// of it leaves its start in slot[0] (atomic min) and its end in slot[STAMP_STRIDE] (atomic max), on the chip-wide 100 MHz
+// clock (s_memrealtime): launch duration = first workgroup's first instruction .. last workgroup's last, with NOTHING
+// added to the stream -- the schedule is the untimed one (an event pair around a launch costs ~5 us of device time and
+// brackets the dispatch gap in front of it; hipExtLaunchKernelGGL's own start / stop events still slow the evaluation
+// by 3 %).  What rocprofv3 adds to this figure is the dispatch's ramp and drain, 1-3 us per launch.  slot == nullptr:
+// one scalar compare per workgroup.
+struct LaunchStamp {
+    unsigned long long* p;
+    // every: stamp one workgroup in `every` (and the last 64 of the grid): a launch of thousands of SHORT workgroups
+    // (k_build: 8256 of ~2 us) would otherwise spend its time queueing 16k atomics on two words (+25 %)
+    __device__ __forceinline__ explicit LaunchStamp(unsigned long long* p_, unsigned every = 1)
+        : p((p_ && (every <= 1 || blockIdx.x % every == 0 || blockIdx.x + 64 >= gridDim.x)) ? p_ : nullptr)
+    {
+        if (p && threadIdx.x == 0)
+            __hip_atomic_fetch_min(p, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __device__ __forceinline__ ~LaunchStamp()
+    {
+        if (p && threadIdx.x == 0)
+            __hip_atomic_fetch_max(p + STAMP_STRIDE, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
+
 // ------------------------------------------------------------------------------------------
 // fp64 MFMA tile product
 // ------------------------------------------------------------------------------------------
@@ -422,8 +446,10 @@ __device__ __forceinline__ void lauum_tile(const double* __restrict__ U, double*
 // workgroup slots that would take a whole tile time -- as four 64x64 workgroups each (split_round below)
 template <int WM>
 __global__ __launch_bounds__(256, 2) void k_lauum(const double* __restrict__ U, double* __restrict__ Kinv, int ld,
-                                                  int a, int w, int nfull, const ExpertPtrs* __restrict__ bt)
+                                                  int a, int w, int nfull, const ExpertPtrs* __restrict__ bt,
+                                                  unsigned long long* stamp)
 {
+    LaunchStamp stamp_(stamp);
     if (bt) { U = GP(bt[blockIdx.y].U); Kinv = GP(bt[blockIdx.y].Kinv); }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     WGT(wgt_, WGT_LAUUM, a);
@@ -504,8 +530,10 @@ __host__ __device__ inline int level_tiles(int nt, int s)
 template <int WM>
 __global__ __launch_bounds__(256, 2) void k_trtri_level(const double* __restrict__ L, double* __restrict__ T,
                                                         double* __restrict__ U, int ld, int nt, int s, int step,
-                                                        size_t off, const ExpertPtrs* __restrict__ bt)
+                                                        size_t off, const ExpertPtrs* __restrict__ bt,
+                                                        unsigned long long* stamp)
 {
+    LaunchStamp stamp_(stamp);
     // off: element offset of the diagonal sub-matrix the level works on (a block of inverse rows)
     if (bt) { L = GP(bt[blockIdx.y].A); T = GP(bt[blockIdx.y].T); U = GP(bt[blockIdx.y].U); }
     L += off; T += off; U += off;
@@ -537,8 +565,10 @@ __device__ __forceinline__ void border_tile(const double* __restrict__ L, double
 template <int WM>
 __global__ __launch_bounds__(256, 2) void k_trtri_border(const double* __restrict__ L, double* __restrict__ T,
                                                          double* __restrict__ U, int ld, int a, int w, int step,
-                                                         int c0, int c1, int nfull, const ExpertPtrs* __restrict__ bt)
+                                                         int c0, int c1, int nfull, const ExpertPtrs* __restrict__ bt,
+                                                         unsigned long long* stamp)
 {
+    LaunchStamp stamp_(stamp);
     if (bt) { L = GP(bt[blockIdx.y].A); T = GP(bt[blockIdx.y].T); U = GP(bt[blockIdx.y].U); }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     WGT(wgt_, WGT_BORDER, a * 4 + step);
@@ -554,8 +584,10 @@ __global__ __launch_bounds__(256, 2) void k_trtri_border(const double* __restric
 
 // ---- prediction: W[t][i] = sum_{k <= i} Ks[t][k] * T[i][k] ----
 __global__ __launch_bounds__(256, 2) void k_predict_gemm(const double* __restrict__ Ks, const double* __restrict__ T,
-                                                         double* __restrict__ W, int ld, int ntt, int nt)
+                                                         double* __restrict__ W, int ld, int ntt, int nt,
+                                                         unsigned long long* stamp)
 {
+    LaunchStamp stamp_(stamp);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tt = blockIdx.x % ntt, ti = blockIdx.x / ntt;
     d4 acc[4][4];
@@ -610,8 +642,10 @@ constexpr int TRSM_SS = 132;                         // ... of the 16 x 128 stri
 constexpr int TRSM_LDS = (64 * TRSM_TS + MT * TRSM_SS + 3 * 4 * 4 * 64) * 8;   // + half sums, X0^T, Z1^T: 76288 B
 
 __global__ __launch_bounds__(512) void k_trsm_inv64(double* __restrict__ A, const double* __restrict__ d64,
-                                                    int ld, int kb, const ExpertPtrs* __restrict__ bt)
+                                                    int ld, int kb, const ExpertPtrs* __restrict__ bt,
+                                                    unsigned long long* stamp)
 {
+    LaunchStamp stamp_(stamp);
     if (bt) { A = GP(bt[blockIdx.y].A); d64 = GP(bt[blockIdx.y].d64); }
     extern __shared__ __attribute__((aligned(16))) double sm[];
     double* Tm = sm;                                    // T00, then -L10, then T11
@@ -794,8 +828,9 @@ __device__ __forceinline__ double div_by(double a, const DivBy& d)
 __global__ __launch_bounds__(256) void k_build(const double* __restrict__ X, int n, int d, int npad,
                                                HyperScalars h_arg, const HyperScalars* __restrict__ hd,
                                                double* __restrict__ K, int full, unsigned* __restrict__ tickets,
-                                               const ExpertPtrs* __restrict__ bt)
+                                               const ExpertPtrs* __restrict__ bt, unsigned long long* stamp)
 {
+    LaunchStamp stamp_(stamp, 16);
     if (bt) {
         X = GP(bt[blockIdx.y].X); n = bt[blockIdx.y].n; K = GP(bt[blockIdx.y].A);
         if (tickets) tickets = GP(bt[blockIdx.y].tickets);
@@ -1591,8 +1626,10 @@ __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, in
                                                       double* __restrict__ d16, double* __restrict__ d64,
                                                       double* __restrict__ logdet_part,
                                                       unsigned* __restrict__ tickets, int nfull, int wcol,
-                                                      int stream_c, const ExpertPtrs* __restrict__ bt)
+                                                      int stream_c, const ExpertPtrs* __restrict__ bt,
+                                                      unsigned long long* stamp)
 {
+    LaunchStamp stamp_(stamp);
     // batched: the EXPERT is the fast grid index, so the diagonal-block workgroups of all experts are
     // dispatched before any tile product (the serial chain of every expert starts at launch)
     const int bid = bt ? blockIdx.y : blockIdx.x;
@@ -1677,8 +1714,9 @@ __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, in
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, 2) void k_syrk_wide(double* __restrict__ A, int ld, int k0, int kw, int ca,
                                                       int cb, int ntiles, int nfull, int rev,
-                                                      const ExpertPtrs* __restrict__ bt)
+                                                      const ExpertPtrs* __restrict__ bt, unsigned long long* stamp)
 {
+    LaunchStamp stamp_(stamp);
     if (bt) A = GP(bt[blockIdx.y].A);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __builtin_amdgcn_s_setprio(1);
@@ -1824,8 +1862,9 @@ __global__ __launch_bounds__(256, 2) void k_trtri_block(const double* __restrict
                                                         double* __restrict__ T, double* __restrict__ U, int ld, int a,
                                                         int wb, unsigned* __restrict__ ctr, double* __restrict__ poison,
                                                         int ctr_off, unsigned spin_cap, double* __restrict__ hstat,
-                                                        const ExpertPtrs* __restrict__ bt)
+                                                        const ExpertPtrs* __restrict__ bt, unsigned long long* stamp)
 {
+    LaunchStamp stamp_(stamp);
     if (bt) {
         const ExpertPtrs& e = bt[blockIdx.y];
         L = GP(e.A); d64 = GP(e.d64); T = GP(e.T); U = GP(e.U); ctr = GP(e.tickets) + ctr_off; poison = GP(e.logdet);
@@ -2093,8 +2132,11 @@ __global__ __launch_bounds__(256) void k_predict_finish(const double* __restrict
 // around the launch, level 3, brackets the ~6 us between the record in front of it and its first workgroup as well
 // and costs ~5 us of device time per pair.)
 thread_local hipEvent_t t_ev0 = nullptr, t_ev1 = nullptr;
+thread_local unsigned long long* t_stamp = nullptr;        // level 5: the next timed launch's slot (LaunchStamp)
 void time_next_launch(hipEvent_t start, hipEvent_t stop) { t_ev0 = start; t_ev1 = stop; }
-bool timing_pending() { return t_ev0 != nullptr; }
+void stamp_next_launch(unsigned long long* slot) { t_stamp = slot; }
+bool timing_pending() { return t_ev0 != nullptr || t_stamp != nullptr; }
+static inline unsigned long long* take_stamp() { unsigned long long* p = t_stamp; t_stamp = nullptr; return p; }
 #define CUGP_LAUNCH(kernel, grid, block, lds, stream, ...)                                          \
     do {                                                                                            \
         if (t_ev0) {                                                                                \
@@ -2115,14 +2157,15 @@ void launch_kbuild(const double* X, int n, int d, int npad, HyperScalars h, doub
                    const HyperScalars* hd, Batch bt, unsigned* tickets)
 {
     hipLaunchKernelGGL(k_build, dim3(tri_count(npad / KT), bt.count), dim3(256), 0, s, X, n, d, npad, h, hd, K,
-                       full ? 1 : 0, tickets, bt.tab);
+                       full ? 1 : 0, tickets, bt.tab, take_stamp());
 }
 
 void launch_sqdist(const double* X, int n, int d, int npad, double c, double* S, hipStream_t s)
 {
     HyperScalars h{c, 0.0, 0.0};
     hipLaunchKernelGGL(k_build, dim3(tri_count(npad / KT)), dim3(256), 0, s, X, n, d, npad, h,
-                       (const HyperScalars*)nullptr, S, 2, (unsigned*)nullptr, (const ExpertPtrs*)nullptr);
+                       (const HyperScalars*)nullptr, S, 2, (unsigned*)nullptr, (const ExpertPtrs*)nullptr,
+                       (unsigned long long*)nullptr);
 }
 
 void launch_kcross(const double* X, int n, int d, int npad, const double* Xt, int nt, int ntpad, HyperScalars h,
@@ -2172,7 +2215,7 @@ void launch_trsm_inv64(double* A, const double* d64, int ld, int kb, int nt, hip
     const int nstrips = (nt - kb - 1) * (TILE / MT);
     if (nstrips <= 0) return;
     set_big_lds();
-    hipLaunchKernelGGL(k_trsm_inv64, dim3(nstrips, bt.count), dim3(512), TRSM_LDS, s, A, d64, ld, kb, bt.tab);
+    hipLaunchKernelGGL(k_trsm_inv64, dim3(nstrips, bt.count), dim3(512), TRSM_LDS, s, A, d64, ld, kb, bt.tab, take_stamp());
 }
 
 void launch_trtri_diag(const double* A, int ld, int kb, int nblocks, const double* d64, double* T, double* U,
@@ -2195,7 +2238,7 @@ int launch_trtri_block(const double* L, const double* d64, double* T, double* U,
     if (G > TRTRI_BLOCK_MAXWG) G = TRTRI_BLOCK_MAXWG;
     if (gcap >= 1 && G > gcap) G = gcap;                  // (every workgroup count gives the same bits: a stage's items are independent)
     CUGP_LAUNCH(k_trtri_block, dim3(G, bt.count), dim3(256), TRTRI_BLOCK_LDS, s, L, d64, T, U, ld, a, wb, ctr,
-                       poison, ctr_off, (unsigned)tune(TUNE_BARRIER_SPIN), hstat, bt.tab);
+                       poison, ctr_off, (unsigned)tune(TUNE_BARRIER_SPIN), hstat, bt.tab, take_stamp());
     return G;
 }
 
@@ -2234,7 +2277,7 @@ void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* d6
     const unsigned nwg = NDIAGWG + nfull + 4 * (ntl - nfull);
     stream_c = (stream_c ? 1 : 0) | ((tune(TUNE_CHAIN) >> 7) & 6);     // (bits 0x100, 0x200: timing experiments)
     CUGP_LAUNCH(k_syrk_step, bt.tab ? dim3(bt.count, nwg) : dim3(nwg), dim3(256), STEP_LDS, s, A, ld, kb, d16,
-                       d64, logdet_part, tickets, nfull, wcol, stream_c, bt.tab);
+                       d64, logdet_part, tickets, nfull, wcol, stream_c, bt.tab, take_stamp());
 }
 
 // tile columns [ca, cb) (rows >= column) -= L(., k0..k0+kw) L(., k0..k0+kw)^T; returns the number of tiles
@@ -2246,7 +2289,7 @@ int launch_syrk_wide(double* A, int ld, int nt, int k0, int kw, int ca, int cb, 
     const int ntiles = trap_count(nt - ca, cb - ca);
     const int nfull = split_round(ntiles, bt.count);
     CUGP_LAUNCH(k_syrk_wide, dim3(nfull + 4 * (ntiles - nfull), bt.count), dim3(256), GEMM_LDS, s, A, ld, k0, kw, ca,
-                       cb, ntiles, nfull, rev, bt.tab);
+                       cb, ntiles, nfull, rev, bt.tab, take_stamp());
     return ntiles;
 }
 
@@ -2265,11 +2308,11 @@ int launch_trtri_level(const double* L, double* T, double* U, int ld, int nt, in
     set_big_lds();
     if (tiles * bt.count <= tune(TUNE_TRTRI_WM2_MAX)) {  // (a batched launch fills the chip with fewer tiles each)
         CUGP_LAUNCH(k_trtri_level<2>, dim3(tiles * 4, bt.count), dim3(256), Geo<2>::LDS, st, L, T, U, ld, nt, s,
-                           step, off, bt.tab);
+                           step, off, bt.tab, take_stamp());
         return 2;
     }
     CUGP_LAUNCH(k_trtri_level<4>, dim3(tiles, bt.count), dim3(256), GEMM_LDS, st, L, T, U, ld, nt, s, step,
-                       off, bt.tab);
+                       off, bt.tab, take_stamp());
     return 4;
 }
 
@@ -2283,12 +2326,12 @@ int launch_trtri_border1(const double* L, double* T, double* U, int ld, int ra, 
     set_big_lds();
     if (tiles * bt.count <= tune(TUNE_BORDER_WM2_MAX)) {
         CUGP_LAUNCH(k_trtri_border<2>, dim3(tiles * 4, bt.count), dim3(256), Geo<2>::LDS, st, L, T, U, ld, ra, rw,
-                           1, c0, c1, 0, bt.tab);
+                           1, c0, c1, 0, bt.tab, take_stamp());
         return 2;
     }
     const int nfull = split_round(tiles, bt.count);
     CUGP_LAUNCH(k_trtri_border<4>, dim3(nfull + 4 * (tiles - nfull), bt.count), dim3(256), GEMM_LDS, st, L, T,
-                       U, ld, ra, rw, 1, c0, c1, nfull, bt.tab);
+                       U, ld, ra, rw, 1, c0, c1, nfull, bt.tab, take_stamp());
     return 4;
 }
 
@@ -2300,12 +2343,12 @@ int launch_trtri_border2(const double* L, double* T, double* U, int ld, int a, i
     set_big_lds();
     if (tiles * bt.count <= tune(TUNE_TRTRI_WM2_MAX)) {
         CUGP_LAUNCH(k_trtri_border<2>, dim3(tiles * 4, bt.count), dim3(256), Geo<2>::LDS, st, L, T, U, ld, a, w, 2,
-                           0, 0, 0, bt.tab);
+                           0, 0, 0, bt.tab, take_stamp());
         return 2;
     }
     const int nfull = split_round(tiles, bt.count);
     CUGP_LAUNCH(k_trtri_border<4>, dim3(nfull + 4 * (tiles - nfull), bt.count), dim3(256), GEMM_LDS, st, L, T,
-                       U, ld, a, w, 2, 0, 0, nfull, bt.tab);
+                       U, ld, a, w, 2, 0, 0, nfull, bt.tab, take_stamp());
     return 4;
 }
 
@@ -2314,14 +2357,14 @@ int launch_lauum(const double* U, double* Kinv, int ld, int a, int w, hipStream_
     set_big_lds();
     const int tiles = tri_count(a + w);
     if (tiles * bt.count <= tune(TUNE_LAUUM_WM2_MAX)) {
-        CUGP_LAUNCH(k_lauum<2>, dim3(tiles * 4, bt.count), dim3(256), Geo<2>::LDS, s, U, Kinv, ld, a, w, 0, bt.tab);
+        CUGP_LAUNCH(k_lauum<2>, dim3(tiles * 4, bt.count), dim3(256), Geo<2>::LDS, s, U, Kinv, ld, a, w, 0, bt.tab, take_stamp());
         return 2;
     } else {
         // (a whole-matrix product, a = 0, has k ranges from 1 to a+w tiles, longest first: its tail is short tiles
         //  already; the split is for the block-wise calls, whose tiles all take w k tiles)
         const int nfull = a > 0 ? split_round(tiles, bt.count) : tiles;
         CUGP_LAUNCH(k_lauum<4>, dim3(nfull + 4 * (tiles - nfull), bt.count), dim3(256), GEMM_LDS, s, U, Kinv, ld,
-                           a, w, nfull, bt.tab);
+                           a, w, nfull, bt.tab, take_stamp());
         return 4;
     }
 }
@@ -2329,7 +2372,7 @@ int launch_lauum(const double* U, double* Kinv, int ld, int a, int w, hipStream_
 void launch_predict_gemm(const double* Ks, const double* T, double* W, int ld, int ntt, int nt, hipStream_t s)
 {
     set_big_lds();
-    CUGP_LAUNCH(k_predict_gemm, dim3(ntt * nt), dim3(256), GEMM_LDS, s, Ks, T, W, ld, ntt, nt);
+    CUGP_LAUNCH(k_predict_gemm, dim3(ntt * nt), dim3(256), GEMM_LDS, s, Ks, T, W, ld, ntt, nt, take_stamp());
 }
 
 void launch_predict_finish(const double* Ks, const double* W, const double* alpha, int n, int npad, int ntest,

@@ -209,11 +209,13 @@ class Covsum:
         return dict(zip(("kbuild", "potrf", "trtri", "lauum", "tail", "total"), ms.tolist()))
 
     def kernel_stats(self, reset=False, kind=0):
-        """HIP-event timings of the Cholesky trailing updates: kind 0 = k_syrk_step, 1 = k_syrk_wide."""
-        s, n, f = C.c_double(), C.c_longlong(), C.c_double()
+        """Per-launch timings of one kernel kind (include/cugp.h: cugp_get_kernel_stats_kind); "disp_ms" (profiling
+        level 5): the same launches from the end of the launch in front of each on its stream."""
+        s, n, f, dms = C.c_double(), C.c_longlong(), C.c_double(), C.c_double()
+        check(capi.lib().cugp_get_kernel_stats_dispatch_ms(self._h, int(kind), C.byref(dms)))
         check(capi.lib().cugp_get_kernel_stats_kind(self._h, int(kind), C.byref(s), C.byref(n), C.byref(f),
                                                     1 if reset else 0))
-        return {"sum_ms": s.value, "launches": n.value, "flop": f.value}
+        return {"sum_ms": s.value, "launches": n.value, "flop": f.value, "disp_ms": dms.value}
 
 
 class BCM:

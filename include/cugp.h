@@ -118,8 +118,11 @@ int cugp_potrs_vec(int n, const double *K, const double *y, double *x, int devic
 int cugp_set_profiling(cugp_gp *gp, int level /* 0 off, 1 phases, 2 phases + HIP events around a rotating sample of the
                                                  MFMA kernels' launches, 3 phases + events around every such launch,
                                                  4 phases + every such launch timed by its OWN start / stop events
-                                                 (hipExtLaunchKernelGGL: the dispatch's begin / end as rocprofv3
-                                                 --kernel-trace reports them, no extra packets on the streams) */);
+                                                 (hipExtLaunchKernelGGL; the start event still sits in front of the
+                                                 dispatch gap and the evaluation runs 3 % slower), 5 phases + every
+                                                 such launch and the covariance build timed by its own workgroups:
+                                                 first start / last end on the chip's 100 MHz clock in a device
+                                                 buffer -- no events, the untimed schedule */);
 int cugp_get_phase_ms(cugp_gp *gp, double ms[6]);
 int cugp_get_kernel_stats(cugp_gp *gp, double *sum_ms, long long *launches, double *flop, int reset);
 /* the same per kernel, as rocprofv3 names them: kind 0 = k_syrk_step (near-window update + next diagonal block,
@@ -127,10 +130,16 @@ int cugp_get_kernel_stats(cugp_gp *gp, double *sum_ms, long long *launches, doub
  * width), 2 / 3 = k_trtri_border<4> / <2> (bordering steps of L^-1) and 4 / 5 = k_lauum<4> / <2> (shares of K^-1):
  * timed for every fourth block of inverse rows, 6 / 7 = k_trtri_level<4> / <2> (doubling inside a block of rows; timed
  * one launch in 16), 8 = k_trtri_block (a hand-over block's own inverse in one launch; every fourth block), 9 =
- * k_predict_gemm (W = Ks L^-T of cugp_predict; levels 3 and 4 only).  The
- * sampling rates are those of level 2; levels 3 and 4 time every launch.  flop = algorithmic
+ * k_predict_gemm (W = Ks L^-T of cugp_predict; levels 3 to 5 only), 10 = k_build (level 5 only; its `flop` is BYTES: the
+ * lower 64x64 tiles of K written once + X read).  The
+ * sampling rates are those of level 2; levels 3 to 5 time every launch.  flop = algorithmic
  * (entries on or below the diagonal, a triangular k tile counted half), multiply + add */
 int cugp_get_kernel_stats_kind(cugp_gp *gp, int kind, double *sum_ms, long long *launches, double *flop, int reset);
+/* level 5 only: the durations of the same launches counted from the END of the launch directly in front of each on its
+ * stream (kind 11 = k_trsm_inv64 -> [k_syrk_wide] -> k_syrk_step on the factorisation's stream), where rocprofv3
+ * --kernel-trace puts the begin of an in-order dispatch -- the launch's wait for its first workgroup slot included;
+ * launches without a stamped predecessor count from their first workgroup.  Read before a resetting call above. */
+int cugp_get_kernel_stats_dispatch_ms(cugp_gp *gp, int kind, double *sum_ms);
 void *cugp_get_stream(cugp_gp *gp);          /* hipStream_t of the handle */
 
 /* ---- optimisers (host logic): Covsum::cg_solve covkernel.cpp:405-647 == cg_solve(BCM)

@@ -279,12 +279,19 @@ def test_config4_si6000_poe_prediction_golden(gp_mod, si24000):
 def _probes_match(tr, c, min_moving):
     """The GPU run's probe points against the reference's PLEASE-SEE trace: one for one while the objective still
     moves (|f - f_final| > 1e-9 |f_final|); where the objective is flat to rounding the direction is noise in any
-    correct implementation (test_cg_trajectory_sine_1024 explains)."""
+    correct implementation (test_cg_trajectory_sine_1024 explains).  The LENGTH of that flat tail is noise as well:
+    the run ends at the second line search in a row that fails (covkernel.cpp:621-637), and whether a probe on a
+    plateau that is constant to 1e-14 "fails" is decided by the last bits of f and of the slope -- round 5 changed the
+    summation order of the tile products once (the C tile is added in the epilogue), and this run then ended after 54
+    probes where the reference's (and round 4's) wandered on to 82, at the same end point and objective.  So the probes
+    are compared over the common prefix, and a run may be shorter or longer than the reference's only once its objective
+    has stopped moving."""
     probes = np.array([p[1:] for p in c["please_see"] if p[0] in (1, 2)])
-    assert tr.shape[0] == probes.shape[0] + 1, (tr.shape, probes.shape)
-    err = np.abs(tr[1:, :3] - probes) / np.maximum(1.0, np.abs(probes))
-    moving = np.abs(tr[1:, 3] + c["final_ll"]) > 1e-9 * abs(c["final_ll"])
+    n = min(tr.shape[0] - 1, probes.shape[0])
+    err = np.abs(tr[1:n + 1, :3] - probes[:n]) / np.maximum(1.0, np.abs(probes[:n]))
+    moving = np.abs(tr[1:n + 1, 3] + c["final_ll"]) > 1e-9 * abs(c["final_ll"])
     assert moving.sum() >= min_moving and np.all(err[moving] <= 5e-5), (int(moving.sum()), float(np.max(err[moving])))
+    assert tr.shape[0] == probes.shape[0] + 1 or not moving[-1], (tr.shape, probes.shape)   # a different length: in the flat tail only
     return err, moving
 
 
