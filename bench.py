@@ -134,6 +134,8 @@ def main():
                     "start / stop events (hipExtLaunchKernelGGL: +3 %% per evaluation, the start event still sits in front of "
                     "the dispatch gap); 3 = an event pair recorded around every such launch (rounds 3-4: ~6 us of dispatch gap "
                     "inside the bracket, ~5 us of device time per pair)")
+    ap.add_argument("--tune", default="", help="comma list key=value of launch-shape keys (cugp_amd/csrc/kernels.h TUNE_*) set as "
+                    "process defaults before any handle exists -- A/B runs only; the contract line is measured without it")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only to rehearse "
                     "the multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses GPU 0")
@@ -170,6 +172,11 @@ def main():
         assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)   # RCCL saw all N ranks
 
     from cugp_amd.bcm import ShardedBCM
+    if args.tune:
+        from cugp_amd import capi
+        for kv in args.tune.split(","):
+            k, v = kv.split("=")
+            capi.check(capi.lib().cugp_set_tuning(int(k), int(v)))
 
     strong = args.experts_total > 0
     K = args.experts_total if strong else world * args.experts_per_gpu
@@ -360,7 +367,7 @@ def main():
                        else "gp_loglik_grad_N%d_D%d" % (args.n, args.d), "experts": K,
                        "experts_per_gpu": (K + world - 1) // world if strong else args.experts_per_gpu,
                        "sharding": "bcm-experts-per-gpu", "overlap": bool(args.overlap) and can_profile,
-                       "hp": HP0.tolist(), "passes": passes,
+                       "hp": HP0.tolist(), "passes": passes, "tune": args.tune or None,
                        "value_from": "timed pass: default path, no per-launch events" if "timed" in passes
                        else "profiled pass (no timed pass was run)"},
             "cholesky_gflops": (npad ** 3 / 3.0) / ((iso_ph or ph)["potrf"] * 1e-3) / 1e9,   # factorisation alone (overlap off)
@@ -452,7 +459,13 @@ def main():
                                       "traffic": pmc.get("k_build", {}).get("hbm_bytes_per_launch"),
                                       "traffic_source": PMC_SUMMARY if "k_build" in pmc else None,
                                       "launch_us": 1e3 * kb_ms, "algorithmic_bytes": nbytes,
-                                      "note": "bound in practice by N^2/2 fp64 exp evaluations, not by HBM"}
+                                      "valu_issue_frac_pmc": pmc.get("k_build", {}).get("valu_issue_frac"),
+                                      "note": "bound by VALU issue, not by HBM or its stores: 52.3 M wave64 vector instructions per "
+                                              "launch (1583 per wave: per matrix entry 30 fp64 ops of the squared distance, "
+                                              "contraction off to match the reference bit for bit, and ~65 of the library exp) x 4 "
+                                              "cycles / 1024 SIMDs = 204 k of the launch's 234 k cycles (87 %); 0.26 M store "
+                                              "instructions, no store-FIFO stalls (profiles/r05_pmc_summary.json, rocprofv3 --pmc "
+                                              "SQ_INSTS_VALU ... SQ_VMEM_WR_TA_DATA_FIFO_FULL)"}
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, args.n), args.n, args.d)
         print(json.dumps(out), flush=True)

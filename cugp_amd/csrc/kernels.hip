@@ -100,7 +100,8 @@ struct LaunchStamp {
     __device__ __forceinline__ explicit LaunchStamp(unsigned long long* p_, unsigned every = 1)
         : p((p_ && (every <= 1 || blockIdx.x % every == 0 || blockIdx.x + 64 >= gridDim.x)) ? p_ : nullptr)
     {
-        if (p && threadIdx.x == 0)
+        // (workgroups are dispatched in index order: the launch's first instruction is one of the first workgroups')
+        if (p && threadIdx.x == 0 && blockIdx.x < 64 && blockIdx.y == 0)
             __hip_atomic_fetch_min(p, (unsigned long long)__builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __device__ __forceinline__ ~LaunchStamp()

@@ -204,3 +204,47 @@ def test_handle_tuning_from_two_threads(gp_mod):
     assert not errs, errs
     for g in hs:
         g.close()
+
+
+def test_profiling_levels_time_the_same_launches_and_change_no_result(gp_mod):
+    """cugp_set_profiling 3 (event pairs around the launches), 4 (the launches' own start / stop events) and 5 (the
+    launches stamped by their own workgroups, nothing added to the streams): the same results as with profiling off, bit
+    for bit, the same launches counted with the same algorithmic flop, durations of the same order; level 5 also times
+    the covariance build (kind 10, its `flop` is bytes) and the panel solves (kind 11), and its dispatch-based duration
+    of a step launch (from the end of the panel solve in front of it) is never below the workgroup-based one."""
+    n = 2600                                              # 21 tiles: hand-over blocks, no two-speed panels
+    g = make(gp_mod, n, 6, 3)
+    g.set_loghyperparam(HP)
+    want = g.loglik_grad()
+    stats = {}
+    for level in (3, 4, 5):
+        g.set_profiling(level)
+        g.set_loghyperparam(HP + 1e-3)
+        g.loglik_grad()
+        for kd in range(12):
+            g.kernel_stats(reset=True, kind=kd)
+        g.set_loghyperparam(HP)
+        ll, gr = g.loglik_grad()
+        assert ll == want[0] and tuple(gr) == tuple(want[1]), level
+        stats[level] = {kd: g.kernel_stats(kind=kd) for kd in range(12)}
+    g.set_profiling(0)
+    for kd in (0, 2, 3, 4, 5, 8):                        # step launches, bordering, K^-1 shares, block inverses
+        a, b, c = stats[3][kd], stats[4][kd], stats[5][kd]
+        assert a["launches"] == b["launches"] == c["launches"], (kd, a, b, c)
+        assert a["flop"] == b["flop"] == c["flop"], kd
+        if a["launches"] > 0:
+            assert 0.3 * a["sum_ms"] <= c["sum_ms"] <= 1.5 * a["sum_ms"], (kd, a, c)
+            assert 0.5 * a["sum_ms"] <= b["sum_ms"] <= 1.5 * a["sum_ms"], (kd, a, b)
+    assert stats[5][0]["launches"] == 20 and stats[5][11]["launches"] == 20      # 20 steps, 20 panel solves
+    assert stats[5][0]["disp_ms"] >= stats[5][0]["sum_ms"] > 0.0
+    kb = stats[5][10]
+    assert kb["launches"] == 1 and kb["flop"] > 8.0 * n * n / 2 and 0.0 < kb["sum_ms"] < 1.0
+    assert stats[3][10]["launches"] == 0 and stats[4][11]["launches"] == 0     # (levels 3, 4 time the MFMA kernels only)
+    # prediction's product is timed from level 3 on (kind 9)
+    g.set_profiling(5)
+    X, _ = synth(64, d=6, seed=9)
+    g.kernel_stats(reset=True, kind=9)
+    g.compute_test_means_and_variances(None, None, X)
+    p = g.kernel_stats(kind=9)
+    assert p["launches"] == 1 and p["sum_ms"] > 0.0 and p["flop"] > 0.0
+    g.close()

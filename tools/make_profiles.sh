@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerate everything under profiles/ for one round on the GPU box:  tools/make_profiles.sh r04
 # Outputs land in gpurun_out/profiles_<tag>/ (copy the ones to keep into profiles/).
-tag=${1:-r04}
+tag=${1:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/profiles_$tag
 mkdir -p $O
@@ -16,6 +16,11 @@ for pass in timed profiled isolated; do
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$pass -- python3 $R/bench.py --passes $pass --cpu-sample 0 --sub-steps 0 > $O/${tag}_bench_${pass}_line_under_rocprof.json 2> $O/bench_$pass.err || exit 1
   cp $(find /tmp/prof_$pass -name '*kernel_stats.csv' | head -1) $O/${tag}_bench_${pass}_n8192_kernel_stats.csv
 done
+# BASELINE config 3's shape (siproper_10000: 79 tiles, 16 rows of identity padding): the bench line and the kernel statistics of its timed pass
+python3 $R/bench.py --rows 10000 --sub-steps 0 --cpu-sample 0 --steps 10 > $O/${tag}_bench_n10000_line.json 2>> $O/bench.err
+rm -rf /tmp/prof_n10000
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_n10000 -- python3 $R/bench.py --rows 10000 --passes timed --steps 10 --cpu-sample 0 --sub-steps 0 > $O/${tag}_bench_n10000_line_under_rocprof.json 2>> $O/bench.err || exit 1
+cp $(find /tmp/prof_n10000 -name '*kernel_stats.csv' | head -1) $O/${tag}_bench_n10000_kernel_stats.csv
 python3 $R/bench.py --rows 1500 --experts-total 16 --cpu-sample 0 > $O/${tag}_bench_bcm16_line.json 2>> $O/bench.err
 python3 $R/bench.py --rows 6000 --experts-total 4 --cpu-sample 0 --steps 10 > $O/${tag}_bench_bcm4_line.json 2>> $O/bench.err
 python3 $R/bench.py --experts-per-gpu 2 --cpu-sample 0 --steps 10 > $O/${tag}_bench_2x8192_line.json 2>> $O/bench.err
@@ -35,7 +40,7 @@ for shape in "expert1500 1500 0" "bcm16x1500 24000 16"; do
   python3 $R/tools/timeline_report.py $(find /tmp/tl_$1 -name '*kernel_trace.csv' | head -1) --launches > $O/${tag}_timeline_$1.txt
 done
 # PMC passes (separate passes; counters only with --kernel-trace)
-for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_LDS_BANK_CONFLICT" "FETCH_SIZE" "WRITE_SIZE"; do
+for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_LDS_BANK_CONFLICT" "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VMEM_WR SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_WAVES"; do
   t=$(echo $pass | cut -d' ' -f1)
   rm -rf $R/gpurun_out/pmc_$t
   rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $R/gpurun_out/pmc_$t -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 --sub-steps 0 --passes timed > $R/gpurun_out/pmc_$t.log 2>&1 || echo "pass $t failed"

@@ -14,7 +14,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out")
-tag = sys.argv[2] if len(sys.argv) > 2 else "r04"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r05"
 CLOCK_HZ, SIMDS = 2.4e9, 256 * 4
 KERNELS = ("k_syrk_step", "k_syrk_wide", "k_lauum<4>", "k_lauum<2>", "k_trtri_level<4>", "k_trtri_level<2>",
            "k_trtri_border<4>", "k_trtri_border<2>", "k_trtri_diag", "k_trtri_block", "k_build", "k_trace", "k_potf2",
@@ -66,6 +66,24 @@ for k, v in sq.items():
     if wc:
         d["wait_inst_any_frac"] = v.get("SQ_WAIT_INST_ANY", 0.0) / wc
         d["lds_bank_conflict_frac"] = v.get("SQ_LDS_BANK_CONFLICT", 0.0) / wc
+# round 5: the VALU pass (what k_build / k_trace are bound by): a wave64 vector instruction holds its SIMD's issue for 4
+# cycles (16 lanes per SIMD), so instructions x 4 / SIMDs against the launch's cycles is the share of the VALU issue used
+vseen = set()
+vdur = collections.defaultdict(float)
+vsum = collections.defaultdict(lambda: collections.defaultdict(float))
+for r in load("SQ_INSTS_VALU"):
+    k = short(r["Kernel_Name"])
+    if k:
+        vsum[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Dispatch_Id"] not in vseen:
+            vseen.add(r["Dispatch_Id"])
+            vdur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
+for k, v in vsum.items():
+    d = out["kernels"].setdefault(k, {})
+    d["valu"] = {n: x for n, x in v.items()}
+    if vdur[k] > 0 and v.get("SQ_INSTS_VALU"):
+        d["valu_issue_frac"] = v["SQ_INSTS_VALU"] * 4.0 / SIMDS / (vdur[k] * CLOCK_HZ)
+        d["valu_per_wave"] = v["SQ_INSTS_VALU"] / v["SQ_WAVES"] if v.get("SQ_WAVES") else None
 for k, d in out["kernels"].items():
     if "fetch_kib_raw" in d and "write_kib" in d and d.get("launches"):
         d["hbm_bytes_per_launch"] = (2.0 * d["fetch_kib_raw"] + d["write_kib"]) * 1024.0 / d["launches"]
