@@ -96,6 +96,7 @@ struct cugp_gp {
     bool factor_valid = false;     // A holds L for (data, hp)
     bool inverse_valid = false;    // T, U, Kinv, alpha hold the inverse quantities for (data, hp)
     bool pending = false, pending_grad = false;
+    bool zfuse = false;            // record_eval, LL-only: the forward substitution L z = y rides in the factorisation's launches
     bool vec_early = false;        // record_eval: z = L^-1 y, alpha = L^-T z go behind the last block's bordering
     bool vec_done = false;         // ... and were enqueued there
     const GroupCtx* grp = nullptr;  // non-null only inside cugp_group_eval
@@ -637,12 +638,13 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false, const unsign
     else if (g->grp) HIPCHK(hipMemsetAsync(g->grp->tickets, 0, (size_t)g->grp->bt.count * 2 * nt * sizeof(unsigned), m));
     else HIPCHK(hipMemsetAsync(g->dtickets, 0, (size_t)2 * nt * sizeof(unsigned), m));
     launch_potf2(g->dA, ld, 0, g->d16, g->d64, g->dlogdet, m, B(g));
+    const bool zf = g->zfuse && !with_inverse;              // (LL-only: z = L^-1 y inside the panel-solve and step launches)
     g->last_main = -1;
     const bool l5 = g->prof >= 5;                           // level 5: every launch of the factorisation's stream is stamped
     for (int kb = 0; kb + 1 < nt; kb++) {
         {
             TimedLaunch tl(g, m, l5, true);
-            launch_trsm_inv64(g->dA, g->d64, ld, kb, nt, m, B(g));
+            launch_trsm_inv64(g->dA, g->d64, ld, kb, nt, m, B(g), zf ? g->dz : nullptr, g->dw);
             tl.done(KIND_TRSM, 2.0 * (nt - kb - 1) * TILE * (double)TILE * TILE / 2);      // (triangular solve: half a product)
         }
         // block rows < kb+1 of L are final, and so are the columns <= kb of every row below them
@@ -663,7 +665,7 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false, const unsign
         // (look-ahead form: plain stores -- the panel solve that follows reads the column at once, and reading
         //  freshly non-temporally stored tiles took it 50 us instead of 16)
         launch_syrk_step(g->dA, ld, kb, nt, g->d16, g->d64, g->dlogdet, g->dtickets, m, B(g), sp.wcol,
-                         P > 1 ? g->tune[TUNE_STEP_STREAM] : 1);
+                         P > 1 ? g->tune[TUNE_STEP_STREAM] : 1, zf ? g->dz : nullptr, g->dw);
         tl.done(KIND_STEP, trailing_flop(nt, kb + 1, kb + 1 + sp.wcol, 1));
         if (hand_over) {
             // The block's own 6-8 launches take the host 15-35 us.  Where a chain step is shorter than that (small
@@ -685,6 +687,10 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false, const unsign
         if ((rc = enqueue_last_block(g, done, nblk))) return rc;      // waits for everything the other streams still do
     } else if (with_inverse) {
         if ((rc = enqueue_inverse_block(g, 0, nt, true, m, nullptr, nullptr))) return rc;
+    } else if (zf) {
+        // the last block's share of z (its diagonal block was factored inside the last step launch); nothing else of the
+        // inverse is needed for a log-likelihood
+        launch_trsm_inv64(g->dA, g->d64, ld, nt - 1, nt, m, B(g), g->dz, g->dw);
     } else {
         // inverses of all diagonal factor blocks at once (off the factorisation's critical path)
         launch_trtri_diag(g->dA, ld, 0, nt, g->d64, g->dT, g->dU, m, B(g));
@@ -729,8 +735,15 @@ int record_eval(cugp_gp* g, bool want_grad, const HyperScalars* hd)
     if ((rc = phase_mark(g, 1))) return rc;
     g->vec_early = want_grad;
     g->vec_done = false;
+    g->zfuse = !want_grad && g->tune[TUNE_ZFUSE] != 0;
+    if (g->zfuse) {                                            // the running right-hand side of the forward substitution: w = y
+        if (g->grp) launch_copy_y_to_w(g->npad, s, B(g));
+        else HIPCHK(hipMemcpyAsync(g->dw, g->dy, (size_t)g->npad * sizeof(double), hipMemcpyDeviceToDevice, s));
+    }
     rc = enqueue_potrf(g, want_grad, true, tickets);           // + L^-1 and K^-1, block rows at a time beside it
     g->vec_early = false;
+    const bool zfused = g->zfuse;
+    g->zfuse = false;
     if (rc) return rc;
     if (want_grad) {
         if ((rc = phase_mark(g, 3))) return rc;              // "trtri" phase = what is left of the inverse blocks
@@ -744,9 +757,11 @@ int record_eval(cugp_gp* g, bool want_grad, const HyperScalars* hd)
     } else {
         if ((rc = phase_mark(g, 3))) return rc;
         if ((rc = phase_mark(g, 4))) return rc;
-        if (g->grp) launch_copy_y_to_w(g->npad, s, B(g));
-        else HIPCHK(hipMemcpyAsync(g->dw, g->dy, (size_t)g->npad * sizeof(double), hipMemcpyDeviceToDevice, s));
-        launch_trsv_lower(g->dA, g->dT, g->npad, g->nt, g->dw, g->dz, s, B(g));   // L z = y
+        if (!zfused) {                                         // (TUNE_ZFUSE = 0: the substitution as 2 nt launches behind the factorisation)
+            if (g->grp) launch_copy_y_to_w(g->npad, s, B(g));
+            else HIPCHK(hipMemcpyAsync(g->dw, g->dy, (size_t)g->npad * sizeof(double), hipMemcpyDeviceToDevice, s));
+            launch_trsv_lower(g->dA, g->dT, g->npad, g->nt, g->dw, g->dz, s, B(g));   // L z = y
+        }
         launch_finalize(g->dz, g->npad, g->n, g->dlogdet, g->nt, nullptr, 0, h, g->dout, host_out(g), s, hd, B(g));
     }
     if ((rc = phase_mark(g, 5))) return rc;

@@ -29,7 +29,8 @@ enum { TUNE_LAUUM_WM2_MAX = 0,   // K^-1 product: use 64x64 tiles when there are
        TUNE_STREAM_PRIO = 15,    // read when a handle is created: bit 0 = the factorisation's stream at the highest priority, bit 1 = the inverse streams at the lowest (default 0: prioritised streams serialised grouped experts in round 3)
        TUNE_BARRIER_SPIN = 16,   // polls a workgroup of k_trtri_block spends at a stage barrier before it gives up (the evaluation then fails with CUGP_ERR_DEVICE instead of hanging); 0 = give up at once (test hook)
        TUNE_CHAIN = 17,          // the factorisation's chain as one resident launch beside the off-chain launches (0 = two launches per step)
-       TUNE_COUNT = 18 };
+       TUNE_ZFUSE = 18,          // LL-only evaluations: the forward substitution L z = y inside the factorisation's launches (1) or as 2 nt launches behind it (0)
+       TUNE_COUNT = 19 };
 extern const int g_tune_init[TUNE_COUNT];     // built-in defaults
 extern thread_local const int* t_tune;        // the tuning the launchers on this thread read (a handle's copy, or the built-in defaults)
 inline int tune(int key) { return t_tune[key]; }
@@ -72,7 +73,10 @@ void launch_kcross(const double* X, int n, int d, int npad, const double* Xt, in
 // d16: 16x16 diagonal inverses [nt][8][256]; d64: the two 64x64 diagonal inverses of each block [nt][2][4096]
 void launch_potf2(double* A, int ld, int kb, double* d16, double* d64, double* logdet_part, hipStream_t s,
                   Batch bt = {});
-void launch_trsm_inv64(double* A, const double* d64, int ld, int kb, int nt, hipStream_t s, Batch bt = {});   // 3-phase, 64x64 inverses
+// zv / wv (when given): the forward substitution L z = y rides along -- one more workgroup computes z_kb = L_kk^-1 w_kb
+// from the block's 64x64 inverses (w: the running right-hand side, y at first); kb = nt - 1 launches that workgroup alone
+void launch_trsm_inv64(double* A, const double* d64, int ld, int kb, int nt, hipStream_t s, Batch bt = {},
+                       double* zv = nullptr, const double* wv = nullptr);   // 3-phase, 64x64 inverses
 void launch_trtri_diag(const double* A, int ld, int kb, int nblocks, const double* d64, double* T, double* U,
                        hipStream_t s, Batch bt = {});
 // inverse of the hand-over block of rows [a, a + wb) in one launch: diagonal-tile inverses + every doubling level inside
@@ -89,7 +93,9 @@ int launch_trtri_block(const double* L, const double* d64, double* T, double* U,
 // trailing update of step kb fused with the factorisation of diagonal block kb+1 (tickets[kb] must be 0)
 // wcol > 0: only the tile columns [kb+1, kb+1+wcol) (two-speed form: the near window)
 void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* d64, double* logdet_part,
-                      unsigned* tickets, hipStream_t s, Batch bt = {}, int wcol = 0, int stream_c = 1);
+                      unsigned* tickets, hipStream_t s, Batch bt = {}, int wcol = 0, int stream_c = 1,
+                      const double* zv = nullptr, double* wv = nullptr);
+                      // zv / wv (when given): nt - kb - 1 more workgroups apply w_i -= L(i,kb) z_kb to the rows below
 // wide trailing update: tile columns [ca, cb) (rows >= column) -= L(., k tiles [k0, k0+kw)) L(.)^T; returns tiles
 int launch_syrk_wide(double* A, int ld, int nt, int k0, int kw, int ca, int cb, int rev, hipStream_t s, Batch bt = {});
 

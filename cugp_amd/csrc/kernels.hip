@@ -642,13 +642,116 @@ constexpr int TRSM_TS = 68;                          // row stride (doubles) of 
 constexpr int TRSM_SS = 132;                         // ... of the 16 x 128 strip
 constexpr int TRSM_LDS = (64 * TRSM_TS + MT * TRSM_SS + 3 * 4 * 4 * 64) * 8;   // + half sums, X0^T, Z1^T: 76288 B
 
+// ---- forward substitution L z = y folded into the factorisation's own launches (round 5; LL-only evaluations) ----
+// z_kb = L_kk^-1 w_kb needs only block kb of the factor and the running right-hand side w; w_i -= L(i,kb) z_kb for the
+// rows below needs only the solved column kb.  Both ride in launches the factorisation makes anyway: ONE extra
+// workgroup of the panel solve of column kb computes z_kb from the block's two 64x64 inverses (zblock_solve: z0 = T00
+// w0, z1 = T11 (w1 - L10 z0)), and nt - kb - 1 extra workgroups of the step launch of column kb apply it to w
+// (vec_update: one wave per row, the per-row order of k_trsv_update).  What used to follow the factorisation as 2 nt
+// small launches (0.56 ms of a 5.5 ms log-likelihood at 8192 rows, 0.10 of 0.54 ms at 1500) is one 1-workgroup launch
+// for the last block.
+__device__ __forceinline__ void zblock_solve(const double* __restrict__ A, const double* __restrict__ d64, int ld, int kb,
+                                             const double* __restrict__ w, double* __restrict__ z, double* __restrict__ sm)
+{
+    // 512 threads: row r = t >> 3 of a 64-row half, column group cg = t & 7 (8 columns each), partial sums over the 8
+    // lanes of a row in a fixed order
+    const int t = threadIdx.x, r = t >> 3, cg = t & 7, k0 = kb * TILE;
+    double* w0 = sm;                                     // w_kb: [0, 64) upper half, [64, 128) lower half
+    double* z0 = sm + 128;
+    double* tt = sm + 192;
+    const double* T00 = d64 + (size_t)kb * 8192;
+    const double* T11 = T00 + 4096;
+    const double* L10 = A + (size_t)(k0 + 64) * ld + k0;
+    // every operand this thread will touch is requested before the first wait: one memory latency for the three
+    // dependent products (requested phase by phase the workgroup took ~12 us and held the panel-solve launch -- on the
+    // factorisation's chain -- 5 us longer than its strips)
+    const int cend = (r | 15) + 1;
+    double a0[8], a1[8], a2[8];
+    const double wmine = t < TILE ? w[k0 + t] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) {
+        const int c = cg * 8 + q;
+        const d2 v0 = *(const d2*)(T00 + r * 64 + c), v1 = *(const d2*)(L10 + (size_t)r * ld + c), v2 = *(const d2*)(T11 + r * 64 + c);
+        // (the 64x64 inverses hold their lower 16x16 micro tiles only: what lies beyond the row's own micro tile is
+        //  never written -- selected away, not multiplied by zero; inside a diagonal micro tile the entries above the
+        //  diagonal are exact zeros)
+        a0[q] = c < cend ? v0[0] : 0.0; a0[q + 1] = c + 1 < cend ? v0[1] : 0.0;
+        a1[q] = v1[0]; a1[q + 1] = v1[1];
+        a2[q] = c < cend ? v2[0] : 0.0; a2[q + 1] = c + 1 < cend ? v2[1] : 0.0;
+    }
+    if (t < TILE) w0[t] = wmine;
+    __syncthreads();
+    auto row_sum = [&](double s) {
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        s += __shfl_xor(s, 4, 64);
+        return s;
+    };
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) s = __builtin_fma(a0[q], w0[cg * 8 + q], s);
+    s = row_sum(s);
+    if (cg == 0) z0[r] = s;
+    __syncthreads();
+    s = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) s = __builtin_fma(a1[q], z0[cg * 8 + q], s);
+    s = row_sum(s);
+    if (cg == 0) tt[r] = w0[64 + r] - s;
+    __syncthreads();
+    s = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) s = __builtin_fma(a2[q], tt[cg * 8 + q], s);
+    s = row_sum(s);
+    if (cg == 0) { z[k0 + r] = z0[r]; z[k0 + 64 + r] = s; }
+}
+
+// w[row] -= L[row][k0 .. k0 + 128) . z[k0 ..) for the 128 rows of tile row `ti` (one wave per row, 32 rows per wave of a
+// 256-thread workgroup): k_trsv_update's arithmetic
+__device__ __forceinline__ void vec_update(const double* __restrict__ A, int ld, int kb, int ti, const double* __restrict__ z,
+                                           double* __restrict__ w)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, k0 = kb * TILE;
+    const d2 xv = *(const d2*)(z + k0 + lane * 2);
+    const double* a = A + (size_t)(ti * TILE + wave * 32) * ld + k0 + lane * 2;
+    // all 32 rows of the wave requested before the first is reduced (row by row the loop was one memory latency per
+    // row: ~45 us per workgroup, longer than the diagonal block the step launch hides)
+    d2 v[32];
+#pragma unroll
+    for (int q = 0; q < 32; q++) v[q] = *(const d2*)(a + (size_t)q * ld);
+    double mine = 0.0;                                   // lane q ends up with row q's sum
+#pragma unroll
+    for (int q = 0; q < 32; q++) {
+        double sum = v[q][0] * xv[0] + v[q][1] * xv[1];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
+        const double tot = __shfl(sum, 0, 64);
+        if (lane == q) mine = tot;
+    }
+    if (lane < 32) {
+        double* wr = w + ti * TILE + wave * 32 + lane;
+        *wr -= mine;
+    }
+}
+
+// zv / wv (when given): the forward substitution rides along -- workgroup `nstrips` of the launch computes z_kb
 __global__ __launch_bounds__(512) void k_trsm_inv64(double* __restrict__ A, const double* __restrict__ d64,
                                                     int ld, int kb, const ExpertPtrs* __restrict__ bt,
-                                                    unsigned long long* stamp)
+                                                    unsigned long long* stamp, int nstrips, double* __restrict__ zvec,
+                                                    const double* __restrict__ wvec)
 {
     LaunchStamp stamp_(stamp);
-    if (bt) { A = GP(bt[blockIdx.y].A); d64 = GP(bt[blockIdx.y].d64); }
+    if (bt) {
+        A = GP(bt[blockIdx.y].A); d64 = GP(bt[blockIdx.y].d64);
+        if (zvec) { zvec = GP(bt[blockIdx.y].z); wvec = GP(bt[blockIdx.y].w); }
+    }
     extern __shared__ __attribute__((aligned(16))) double sm[];
+    // (zvec given: workgroup 0 -- dispatched first -- is the vector workgroup, the strips follow)
+    const int strip = zvec ? (int)blockIdx.x - 1 : (int)blockIdx.x;
+    if (strip < 0) {
+        zblock_solve(A, d64, ld, kb, wvec, zvec, sm);
+        return;
+    }
     double* Tm = sm;                                    // T00, then -L10, then T11
     double* Sb = Tm + 64 * TRSM_TS;                     // the strip: A in, X out (row-major)
     double* Sc = Sb + MT * TRSM_SS;                     // half sums of the waves h = 1: [w][r][lane]
@@ -659,7 +762,7 @@ __global__ __launch_bounds__(512) void k_trsm_inv64(double* __restrict__ A, cons
     const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
     const int w = wv & 3, h = wv >> 2, c = lane & 15, g = lane >> 4;
     const int k0 = kb * TILE;
-    double* Ag = A + (size_t)(k0 + TILE + blockIdx.x * MT) * ld + k0;
+    double* Ag = A + (size_t)(k0 + TILE + strip * MT) * ld + k0;
     const double* T00 = d64 + (size_t)kb * 8192;
     const double* T11 = T00 + 4096;
     const double* L10 = A + (size_t)(k0 + 64) * ld + k0;
@@ -1628,7 +1731,8 @@ __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, in
                                                       double* __restrict__ logdet_part,
                                                       unsigned* __restrict__ tickets, int nfull, int wcol,
                                                       int stream_c, const ExpertPtrs* __restrict__ bt,
-                                                      unsigned long long* stamp)
+                                                      unsigned long long* stamp, int vec0, const double* __restrict__ zv,
+                                                      double* __restrict__ wv)
 {
     LaunchStamp stamp_(stamp);
     // batched: the EXPERT is the fast grid index, so the diagonal-block workgroups of all experts are
@@ -1637,6 +1741,13 @@ __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, in
     if (bt) {
         const ExpertPtrs& e = bt[blockIdx.x];
         A = GP(e.A); d16 = GP(e.d16); d64 = GP(e.d64); logdet_part = GP(e.logdet); tickets = GP(e.tickets);
+        if (zv) { zv = GP(e.z); wv = GP(e.w); }
+    }
+    // workgroups from vec0 on (only launched when zv is given): the forward substitution's update of the running
+    // right-hand side with the column this step consumes, one workgroup per tile row below it
+    if (zv && bid >= vec0) {
+        vec_update(A, ld, kb, kb + 1 + (bid - vec0), zv, wv);
+        return;
     }
     extern __shared__ __attribute__((aligned(16))) double sm[];
     __shared__ double red[TILE + 4 * MT];
@@ -2149,7 +2260,7 @@ static inline unsigned long long* take_stamp() { unsigned long long* p = t_stamp
         }                                                                                           \
     } while (0)
 
-const int g_tune_init[TUNE_COUNT] = {768, 1200, 384, -1, 511, 1, 1, 1 << 20, 16, 500, 32, 1, 1, 256, 1536, 0, 1 << 21, 0};   // defaults chosen by interleaved A/B runs (tools/ab.py)
+const int g_tune_init[TUNE_COUNT] = {768, 1200, 384, -1, 511, 1, 1, 1 << 20, 16, 500, 32, 1, 1, 256, 1536, 0, 1 << 21, 0, 1};   // defaults chosen by interleaved A/B runs (tools/ab.py)
 thread_local const int* t_tune = g_tune_init;
 
 static inline int tri_count(int n) { return n * (n + 1) / 2; }
@@ -2211,12 +2322,14 @@ void launch_potf2(double* A, int ld, int kb, double* d16, double* d64, double* l
     hipLaunchKernelGGL(k_potf2, dim3(1, bt.count), dim3(256), POTF2_LDS, s, A, ld, kb, d16, d64, logdet_part, bt.tab);
 }
 
-void launch_trsm_inv64(double* A, const double* d64, int ld, int kb, int nt, hipStream_t s, Batch bt)
+void launch_trsm_inv64(double* A, const double* d64, int ld, int kb, int nt, hipStream_t s, Batch bt, double* zv,
+                       const double* wv)
 {
     const int nstrips = (nt - kb - 1) * (TILE / MT);
-    if (nstrips <= 0) return;
+    if (nstrips <= 0 && !zv) return;                      // (kb = nt - 1 with zv: the last block's z alone)
     set_big_lds();
-    hipLaunchKernelGGL(k_trsm_inv64, dim3(nstrips, bt.count), dim3(512), TRSM_LDS, s, A, d64, ld, kb, bt.tab, take_stamp());
+    hipLaunchKernelGGL(k_trsm_inv64, dim3(nstrips + (zv ? 1 : 0), bt.count), dim3(512), TRSM_LDS, s, A, d64, ld, kb, bt.tab,
+                       take_stamp(), nstrips, zv, wv);
 }
 
 void launch_trtri_diag(const double* A, int ld, int kb, int nblocks, const double* d64, double* T, double* U,
@@ -2260,7 +2373,7 @@ static inline int trap_count(int m, int wcol)          // tiles (ti >= tj) of th
 }
 
 void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* d64, double* logdet_part,
-                      unsigned* tickets, hipStream_t s, Batch bt, int wcol, int stream_c)
+                      unsigned* tickets, hipStream_t s, Batch bt, int wcol, int stream_c, const double* zv, double* wv)
 {
     const int m = nt - kb - 1;
     if (m <= 0) return;
@@ -2275,10 +2388,11 @@ void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* d6
     // per ~138 cycles (one wave per SIMD: half the pipe's rate) and takes ~40 us -- as long as the diagonal block
     // inside this launch.  As 64x64 quarters the same tiles take ~12 us per round of 512 workgroups.
     if ((long long)ntl * bt.count * 4 <= tune(TUNE_STEP_QUARTER_MAX)) nfull = 0;
-    const unsigned nwg = NDIAGWG + nfull + 4 * (ntl - nfull);
+    const int vec0 = NDIAGWG + nfull + 4 * (ntl - nfull);
+    const unsigned nwg = vec0 + (zv ? m : 0);
     stream_c = (stream_c ? 1 : 0) | ((tune(TUNE_CHAIN) >> 7) & 6);     // (bits 0x100, 0x200: timing experiments)
     CUGP_LAUNCH(k_syrk_step, bt.tab ? dim3(bt.count, nwg) : dim3(nwg), dim3(256), STEP_LDS, s, A, ld, kb, d16,
-                       d64, logdet_part, tickets, nfull, wcol, stream_c, bt.tab, take_stamp());
+                       d64, logdet_part, tickets, nfull, wcol, stream_c, bt.tab, take_stamp(), vec0, zv, wv);
 }
 
 // tile columns [ca, cb) (rows >= column) -= L(., k0..k0+kw) L(., k0..k0+kw)^T; returns the number of tiles

@@ -12,7 +12,7 @@ from conftest import synth
 pytestmark = pytest.mark.gpu
 
 HP = np.array([np.log(3.0), 0.0, np.log(0.1)])
-TUNE_PIPE_BLOCK, TUNE_BARRIER_SPIN = 3, 16
+TUNE_PIPE_BLOCK, TUNE_BARRIER_SPIN, TUNE_ZFUSE = 3, 16, 18
 
 
 @pytest.fixture(scope="module")
@@ -248,3 +248,82 @@ def test_profiling_levels_time_the_same_launches_and_change_no_result(gp_mod):
     p = g.kernel_stats(kind=9)
     assert p["launches"] == 1 and p["sum_ms"] > 0.0 and p["flop"] > 0.0
     g.close()
+
+
+@pytest.mark.parametrize("n", [100, 130, 515, 1500, 2600, 4200])
+def test_forward_substitution_inside_the_factorisation(gp_mod, oracle, n):
+    """LL-only evaluations (Covsum::compute_loglikelihood, covkernel.cpp:118-129: Cholesky, then L z = y by
+    matrixops.cpp:113-185's forward sweep): since round 5 z is computed inside the factorisation's own launches (one more
+    workgroup per panel solve, nt - kb - 1 more per step launch; TUNE_ZFUSE = 1) instead of by 2 nt small launches behind
+    it.  Same quadratic form and log-determinant as the launch-by-launch substitution to rounding (the diagonal blocks
+    are applied as two 64x64 inverses instead of one 128x128 inverse), the same as the gradient path's z = L^-1 y, and the
+    oracle's to 1e-8.  1 tile, 2 tiles, ragged, config-5 size, many hand-over blocks, the two-speed factorisation."""
+    X, y = synth(n, d=6, seed=n)
+    g = gp_mod.Covsum(n, 6)
+    g.set_data(X, y)
+    res = {}
+    for mode in (1, 0):
+        g.set_tuning(TUNE_ZFUSE, mode)
+        g.set_loghyperparam(HP + 1e-3)
+        g.compute_loglikelihood()
+        g.set_loghyperparam(HP)
+        ll = g.compute_loglikelihood()
+        res[mode] = (ll,) + g.last_quad_logdet()
+    assert res[1][2] == res[0][2]                                        # the same factor: the same log-determinant
+    assert abs(res[1][1] - res[0][1]) <= 1e-12 * abs(res[0][1]), res     # y' K^-1 y
+    assert abs(res[1][0] - res[0][0]) <= 1e-12 * abs(res[0][0]), res
+    g.set_loghyperparam(HP + 1e-3)
+    g.loglik_grad()
+    g.set_loghyperparam(HP)
+    ll_g, _ = g.loglik_grad()
+    assert abs(ll_g - res[1][0]) <= 1e-11 * abs(ll_g), (ll_g, res[1][0])
+    if n <= 1500:
+        llo = oracle.loglik(X, y, HP)
+        assert abs(res[1][0] - llo) <= 1e-8 * max(1.0, abs(llo)), (res[1][0], llo)
+    # twice the same: bit-reproducible
+    g.set_tuning(TUNE_ZFUSE, 1)
+    g.set_loghyperparam(HP + 1e-3)
+    g.compute_loglikelihood()
+    g.set_loghyperparam(HP)
+    assert g.compute_loglikelihood() == res[1][0]
+    g.close()
+
+
+def test_forward_substitution_in_a_group(gp_mod):
+    """The same for experts that share launches (blockIdx.y = expert; group.h's internal entry points, which the BCM
+    layer drives with the gradient on): an LL-only group evaluation, fused against the launch-by-launch substitution and
+    against every expert evaluated alone."""
+    import ctypes as C
+    from cugp_amd import capi
+    L = capi.lib()
+    X, y = synth(4 * 700 + 11, d=5, seed=8)
+    b = gp_mod.BCM.split(X, y, 4)
+    b.set_BCM_log_hyperparam(HP)
+    hs = (C.c_void_p * 4)(*[b.expert(k)._h for k in range(4)])
+    grp = C.c_void_p()
+    L.cugp_group_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]
+    L.cugp_group_eval.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.cugp_group_destroy.argtypes = [C.c_void_p]
+    L.cugp_group_destroy.restype = None
+    capi.check(L.cugp_group_create(hs, 4, C.byref(grp)))
+    vals = {}
+    try:
+        for mode in (1, 0):
+            capi.check(L.cugp_set_tuning(TUNE_ZFUSE, mode))
+            ll = (C.c_double * 4)()
+            b.set_BCM_log_hyperparam(HP + 1e-3)
+            capi.check(L.cugp_group_eval(grp, 0, ll, None))
+            b.set_BCM_log_hyperparam(HP)
+            capi.check(L.cugp_group_eval(grp, 0, ll, None))
+            vals[mode] = np.array(list(ll))
+    finally:
+        capi.check(L.cugp_set_tuning(TUNE_ZFUSE, 1))
+        L.cugp_group_destroy(grp)
+    assert np.all(np.abs(vals[1] - vals[0]) <= 1e-12 * np.abs(vals[0])), vals
+    for k in range(4):
+        e = b.expert(k)
+        e.set_loghyperparam(HP + 1e-3)
+        e.compute_loglikelihood()
+        e.set_loghyperparam(HP)
+        assert e.compute_loglikelihood() == vals[1][k], k               # alone (same padded size): the same bits
+    b.close()
