@@ -303,7 +303,7 @@ def main():
         first.set_profiling(0)
         if pst["launches"] > 0:
             pach = pst["flop"] / (pst["sum_ms"] * 1e-3) / 1e12
-            predict["roofline"] = {"kernel": "k_predict_gemm (W = Ks L^-T, K = 128 (ti + 1) per output tile; fp64 MFMA 16x16x4)",
+            predict["roofline"] = {"kernel": "k_predict_gemm (W = Ks L^-T, 64x64 output tiles in pairs of equal total K; fp64 MFMA 16x16x4)",
                                    "bound": "mfma", "achieved": pach, "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                    "frac": pach / MFMA_F64_PEAK_TFLOPS, "avg_launch_us": 1e3 * pst["sum_ms"] / pst["launches"],
                                    "algorithmic_flop_per_launch": pst["flop"] / pst["launches"],

@@ -584,17 +584,28 @@ __global__ __launch_bounds__(256, 2) void k_trtri_border(const double* __restric
 }
 
 // ---- prediction: W[t][i] = sum_{k <= i} Ks[t][k] * T[i][k] ----
+// T = L^-1 is lower triangular: row tile i needs k < (i + 1) * tile only, so the work per output tile grows linearly
+// with i.  Rounds 1-4 gave every 128x128 output tile a workgroup of its own: 512 workgroups for 1000 test points at
+// N = 8192, one round of the chip, whose duration is the LONGEST tile's (K = 8192) while the average is half of it --
+// 45 TF/s = 0.58 of peak.  Round 5: 64x64 output tiles in PAIRS (row tile p with row tile n64 - 1 - p, the long one
+// first): every workgroup does K = (n64 + 1) * 64 in all, 1024 equal workgroups, four per CU.  The same per-element
+// sums in the same order (the k range of a tile ends at its own diagonal; what the 128-tile form added beyond it were
+// exact zeros of T): bit-identical results.
 __global__ __launch_bounds__(256, 2) void k_predict_gemm(const double* __restrict__ Ks, const double* __restrict__ T,
-                                                         double* __restrict__ W, int ld, int ntt, int nt,
+                                                         double* __restrict__ W, int ld, int ntt64, int n64,
                                                          unsigned long long* stamp)
 {
     LaunchStamp stamp_(stamp);
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tt = blockIdx.x % ntt, ti = blockIdx.x / ntt;
-    d4 acc[4][4];
-    acc_zero(acc);
-    tile_nt<false>(Ks + (size_t)tt * TILE * ld, ld, T + (size_t)ti * TILE * ld, ld, 0, (ti + 1) * TILE, acc, smem);
-    tile_store(W + (size_t)tt * TILE * ld + ti * TILE, ld, acc, 1.0);
+    const int tt = blockIdx.x % ntt64, p = blockIdx.x / ntt64;
+#pragma unroll 1
+    for (int h = 0; h < 2; h++) {
+        const int ti = h == 0 ? n64 - 1 - p : p;
+        d4 acc[2][2];
+        acc_zero(acc);
+        tile_nt<false>(Ks + (size_t)tt * 64 * ld, ld, T + (size_t)ti * 64 * ld, ld, 0, (ti + 1) * 64, acc, smem);
+        tile_store(W + (size_t)tt * 64 * ld + ti * 64, ld, acc, 1.0);
+    }
 }
 
 // ---- plain NT product for tests ----
@@ -2305,7 +2316,7 @@ static void set_big_lds()
     attr((const void*)k_syrk_step, STEP_LDS);
     attr((const void*)k_syrk_wide, GEMM_LDS);
     const void* gemm4[] = {(const void*)k_trtri_level<4>, (const void*)k_trtri_border<4>, (const void*)k_lauum<4>,
-                           (const void*)k_predict_gemm, (const void*)k_test_gemm};
+                           (const void*)k_test_gemm};
     for (const void* f : gemm4) attr(f, GEMM_LDS);
     attr((const void*)k_trtri_diag, TRTRI_LDS);
     attr((const void*)k_trtri_block, TRTRI_BLOCK_LDS);
@@ -2487,7 +2498,8 @@ int launch_lauum(const double* U, double* Kinv, int ld, int a, int w, hipStream_
 void launch_predict_gemm(const double* Ks, const double* T, double* W, int ld, int ntt, int nt, hipStream_t s)
 {
     set_big_lds();
-    CUGP_LAUNCH(k_predict_gemm, dim3(ntt * nt), dim3(256), GEMM_LDS, s, Ks, T, W, ld, ntt, nt, take_stamp());
+    // (ntt, nt in 128-row tiles; the kernel works on 64-row tiles in pairs)
+    CUGP_LAUNCH(k_predict_gemm, dim3(2 * ntt * nt), dim3(256), Geo<2>::LDS, s, Ks, T, W, ld, 2 * ntt, 2 * nt, take_stamp());
 }
 
 void launch_predict_finish(const double* Ks, const double* W, const double* alpha, int n, int npad, int ntest,
