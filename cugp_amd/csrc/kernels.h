@@ -23,7 +23,7 @@ enum { TUNE_LAUUM_WM2_MAX = 0,   // K^-1 product: use 64x64 tiles when there are
        TUNE_NEAR_TILES = 9,      // ... tiles in the near window (updated every step, K = 128) at a panel's first step
        TUNE_PANEL_MIN_NT = 10,   // ... only from this many tiles on (small matrices are bound by the chain alone)
        TUNE_LAUUM_STREAM = 11,   // the K^-1 share of an inverse block on its own stream beside the next block's bordering: 0 never, 1 expert groups only, 2 always
-       TUNE_STEP_STREAM = 12,    // two-speed step kernel: non-temporal accesses to the C tiles (1) or plain ones (0)
+       TUNE_STEP_STREAM = 12,    // (no effect since round 5: the C tile of every accumulate-form product is read and written in the epilogue with plain accesses -- non-temporal ones lost 1-3 TF/s there; rounds 2-4: non-temporal accesses to the step kernel's C tiles)
        TUNE_SPLIT_REM_MAX = 13,  // uniform-K launches (block-wise K^-1 share, bordering, wide update): a last round of at most this many tiles runs as 64x64 quarters
        TUNE_STEP_QUARTER_MAX = 14, // step kernel: launches of at most this many 64x64 workgroups run ALL their tiles as quarters (chain-bound tail)
        TUNE_STREAM_PRIO = 15,    // read when a handle is created: bit 0 = the factorisation's stream at the highest priority, bit 1 = the inverse streams at the lowest (default 0: prioritised streams serialised grouped experts in round 3)

@@ -285,7 +285,8 @@ __device__ __forceinline__ void acc_zero(d4 (&acc)[WM][WM])
 #define ACC_ROW(m, r) (wr * 16 * WM + (m) * 16 + (lane >> 4) + 4 * (r))
 #define ACC_COL2(np) (wc * 16 * WM + (np) * 32 + 2 * (lane & 15))
 
-// acc = C   (the K loop then accumulates straight onto it: no read-modify-write epilogue)
+// acc = C   (the K loop then accumulates straight onto it: no read-modify-write epilogue).  The product form of rounds
+// 1-4; since round 5 the library's kernels use tile_accum_store below (tools/wide_bench.hip keeps both side by side).
 // STREAM: the tile is touched once per launch -> non-temporal accesses keep the shared operand panels in L2
 template <bool STREAM = false, int WM>
 __device__ __forceinline__ void tile_load(const double* __restrict__ C, int ldc, d4 (&acc)[WM][WM])
