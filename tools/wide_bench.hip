@@ -39,6 +39,62 @@ __device__ __forceinline__ void tile_sub_store(double* __restrict__ C, int ldc, 
     }
 }
 
+// the same with the loads of row group m + 1 issued BEFORE row group m is updated and stored (two groups in flight)
+template <int WM>
+__device__ __forceinline__ void tile_sub_store_db(double* __restrict__ C, int ldc, const d4 (&acc)[WM][WM])
+{
+    const int tid = opaque_tid();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    d2 v[2][4][WM / 2];
+    auto load = [&](int m, d2 (&dst)[4][WM / 2]) {
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int np = 0; np < WM / 2; np++)
+                dst[r][np] = *(const d2*)(C + (size_t)ACC_ROW(m, r) * ldc + ACC_COL2(np));
+    };
+    load(0, v[0]);
+#pragma unroll
+    for (int m = 0; m < WM; m++) {
+        if (m + 1 < WM) load(m + 1, v[(m + 1) & 1]);
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int np = 0; np < WM / 2; np++) {
+                d2* dst = (d2*)(C + (size_t)ACC_ROW(m, r) * ldc + ACC_COL2(np));
+                *dst = (d2){v[m & 1][r][np][0] - acc[m][2 * np][r], v[m & 1][r][np][1] - acc[m][2 * np + 1][r]};
+            }
+    }
+}
+
+// all four row groups requested at once, then updated and stored (needs 64 more registers: may not fit beside the accumulators)
+template <int WM>
+__device__ __forceinline__ void tile_sub_store_all(double* __restrict__ C, int ldc, const d4 (&acc)[WM][WM])
+{
+    const int tid = opaque_tid();
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    d2 v[WM][4][WM / 2];
+#pragma unroll
+    for (int m = 0; m < WM; m++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int np = 0; np < WM / 2; np++)
+                v[m][r][np] = *(const d2*)(C + (size_t)ACC_ROW(m, r) * ldc + ACC_COL2(np));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < WM; m++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+#pragma unroll
+            for (int np = 0; np < WM / 2; np++) {
+                d2* dst = (d2*)(C + (size_t)ACC_ROW(m, r) * ldc + ACC_COL2(np));
+                *dst = (d2){v[m][r][np][0] - acc[m][2 * np][r], v[m][r][np][1] - acc[m][2 * np + 1][r]};
+            }
+}
+
 // MODE 0: the product's form (accumulators from C, K loop, store); 1: C in the epilogue, non-temporal; 2: the same
 // with plain accesses; 3: no C read at all (timing only: what the read costs); 4: neither read nor write (timing only)
 template <int MODE>
@@ -63,6 +119,8 @@ __global__ __launch_bounds__(256, 2) void k_wide_var(double* __restrict__ A, int
         tile_nt<false>(A + (size_t)i0 * ld, ld, A + (size_t)j0 * ld, ld, k0 * TILE, (k0 + kw) * TILE, acc, smem);
         if (MODE == 1) tile_sub_store<true>(C, ld, acc);
         else if (MODE == 2) tile_sub_store<false>(C, ld, acc);
+        else if (MODE == 5) tile_sub_store_db(C, ld, acc);
+        else if (MODE == 6) tile_sub_store_all(C, ld, acc);
         else if (MODE == 3) tile_store<true>(C, ld, acc, -1e-300);
         else if (acc[0][0][0] == 12345.678) tile_store<true>(C, ld, acc, 1.0);
     }
@@ -117,12 +175,13 @@ int main(int argc, char** argv)
     // round 5: the C tile in front of the K loop (0) or in the epilogue (1 non-temporal, 2 plain), and what it costs (3, 4)
     {
         typedef int (*Fn)(double*, int, int, int, int, int, int, int);
-        const Fn fns[] = {launch_wide_var<0>, launch_wide_var<1>, launch_wide_var<2>, launch_wide_var<3>, launch_wide_var<4>};
-        const char* nm[] = {"acc from C (product form)", "C in the epilogue, nt", "C in the epilogue, plain", "no C read (timing only)", "no C read, no write (timing only)"};
+        const Fn fns[] = {launch_wide_var<0>, launch_wide_var<1>, launch_wide_var<2>, launch_wide_var<3>, launch_wide_var<4>, launch_wide_var<5>, launch_wide_var<6>};
+        const char* nm[] = {"acc from C (product form)", "C in the epilogue, nt", "C in the epilogue, plain", "no C read (timing only)", "no C read, no write (timing only)",
+                            "epilogue, two row groups in flight", "epilogue, all four requested at once"};
         const Case vc[] = {{0, 1, 8, 64}, {0, 2, 8, 64}, {0, 4, 8, 64}, {0, 4, 19, 64}, {0, 8, 8, 64}, {0, 16, 19, 64}};
         for (const Case& c : vc)
             for (int rep = 0; rep < 2; rep++)
-                for (int m = 0; m < 5; m++) {
+                for (int m = 0; m < 7; m++) {
                     int tiles = fns[m](A, n, nt, c.k0, c.kw, c.ca, c.cb, 0);
                     hipDeviceSynchronize();
                     hipEventRecord(a);
