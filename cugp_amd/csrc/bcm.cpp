@@ -33,6 +33,8 @@ struct cugp_bcm {
     std::vector<int> rows;
     int d = 0;
     double hp[3] = {0, 0, 0};
+    double* pred_host = nullptr;     // pinned: [expert][mean nt | variance nt] of the prediction in flight
+    size_t pred_cap = 0;             // ... in doubles
 };
 
 extern "C" {
@@ -123,6 +125,7 @@ int cugp_bcm_destroy(cugp_bcm* b)
     if (!b) return CUGP_OK;
     for (DeviceSet& ds : b->sets) cugp_group_destroy(ds.group);
     for (cugp_gp* g : b->experts) cugp_destroy(g);
+    if (b->pred_host) (void)hipHostFree(b->pred_host);
     delete b;
     return CUGP_OK;
 }
@@ -301,11 +304,40 @@ int cugp_bcm_loglik_grad(cugp_bcm* b, double* ll, double g[3], double* per_exper
 int cugp_bcm_predict_partial(cugp_bcm* b, const double* Xt, int nt, double* sum_prec, double* sum_prec_mean)
 {
     if (!b || !Xt || nt <= 0 || !sum_prec || !sum_prec_mean) return CUGP_ERR_INVALID;
-    std::vector<double> m(nt), v(nt);
+    int rc;
+    // Round 5.  (1) Experts whose inverse quantities are not valid for the current hyper-parameters (a prediction right
+    // after set_BCM_log_hyperparam, BCM.cpp:64-83 after :123-130) are brought up to date by ONE evaluation of the whole
+    // model -- the groups of shared launches -- instead of one by one inside cugp_predict (16 x 1500 rows: 18 ms -> one
+    // 2 ms evaluation), and every prediction then sees the experts in the state a BCM evaluation leaves them in,
+    // whatever came before.  (2) All experts' predictions are in flight before the first is read: each on its own
+    // stream, results into one pinned buffer; the two product-of-experts sums are taken in expert order (BCM.cpp:45-62).
+    bool stale = false;
+    for (cugp_gp* e : b->experts) stale = stale || !cugp_has_inverse(e);
+    if (stale) {
+        double ll, g3[3];
+        if ((rc = cugp_bcm_loglik_grad(b, &ll, g3, nullptr))) return rc;
+    }
+    const size_t K = b->experts.size(), need = K * 2 * (size_t)nt;
+    if (need > b->pred_cap) {
+        if (b->pred_host) (void)hipHostFree(b->pred_host);
+        b->pred_host = nullptr;
+        b->pred_cap = 0;
+        if (hipHostMalloc((void**)&b->pred_host, need * sizeof(double), hipHostMallocDefault) != hipSuccess) return CUGP_ERR_NOMEM;
+        b->pred_cap = need;
+    }
+    size_t enq = 0;
+    rc = CUGP_OK;
+    for (; enq < K && rc == CUGP_OK; enq++) rc = cugp_predict_enqueue(b->experts[enq], Xt, nt, b->pred_host + enq * 2 * nt);
+    if (rc) enq--;                                          // (the failing one enqueued nothing that needs a fetch)
+    for (size_t k = 0; k < enq; k++) {
+        const int rf = cugp_predict_fetch(b->experts[k]);
+        if (rf && rc == CUGP_OK) rc = rf;
+    }
+    if (rc) return rc;
     for (int i = 0; i < nt; i++) sum_prec[i] = sum_prec_mean[i] = 0.0;
-    for (cugp_gp* e : b->experts) {
-        int rc = cugp_predict(e, Xt, nt, m.data(), v.data());
-        if (rc) return rc;
+    for (size_t k = 0; k < K; k++) {
+        const double* m = b->pred_host + k * 2 * nt;
+        const double* v = m + nt;
         for (int i = 0; i < nt; i++) {                   // BCM.cpp:51-55
             const double inv = 1.0 / v[i];
             sum_prec[i] += inv;

@@ -1129,6 +1129,7 @@ static int predict_device(cugp_gp* g, const double* Xt, int nt, double** dmean_o
 {
     int rc;
     if ((rc = cugp_loglik_grad(g, nullptr, nullptr))) return rc;     // factor, T, alpha for the current hp
+    if ((rc = use_device(g))) return rc;                             // (a BCM over several devices predicts expert by expert)
     const int ntpad = ((nt + TILE - 1) / TILE) * TILE;
     const HyperScalars h = scalars(g);
     // prediction scratch lives with the handle and only grows (the allocations cost more than the kernels
@@ -1183,6 +1184,30 @@ int cugp_predict(cugp_gp* g, const double* Xt, int nt, double* mean, double* var
     (void)hipStreamSynchronize(g->stream);
     for (double* p : tmp) (void)hipFree(p);
     return rc;
+}
+
+int cugp_has_inverse(const cugp_gp* g) { return g && !g->pending && g->inverse_valid ? 1 : 0; }
+
+int cugp_predict_enqueue(cugp_gp* g, const double* Xt, int nt, double* host_mv)
+{
+    if (!g || !Xt || !host_mv || nt <= 0) return fail(CUGP_ERR_INVALID, "cugp_predict_enqueue: bad argument");
+    std::vector<double*> tmp;
+    double *dm = nullptr, *dv = nullptr;
+    int rc = predict_device(g, Xt, nt, &dm, &dv, tmp);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(host_mv, dm, (size_t)nt * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+    HIPCHK(hipMemcpyAsync(host_mv + nt, dv, (size_t)nt * sizeof(double), hipMemcpyDeviceToHost, g->stream));
+    return CUGP_OK;
+}
+
+int cugp_predict_fetch(cugp_gp* g)
+{
+    if (!g) return CUGP_ERR_INVALID;
+    int rc;
+    if ((rc = use_device(g))) return rc;
+    HIPCHK(hipStreamSynchronize(g->stream));
+    if (g->prof >= 2) drain_kernel_events(g);
+    return CUGP_OK;
 }
 
 // ---------------------------------------------------------------- intermediates

@@ -25,4 +25,12 @@ int cugp_group_device_results(cugp_group* gr, const double** dout, void** stream
 // 4 doubles device -> device on `stream` (hipStream_t); the result row of the evaluation a single expert has in flight
 int cugp_copy_device_row(double* dst, const double* src, void* stream);
 int cugp_copy_result_row(cugp_gp* gp, double* dst);
+// the handle holds L^-1, K^-1, alpha for its current data and hyper-parameters (what a prediction needs)
+int cugp_has_inverse(const cugp_gp* gp);
+// prediction in two halves, so that the experts of a BCM are all in flight before the first result is read: enqueue
+// builds the cross-covariance, its product with L^-T and the means / variances on the handle's stream and copies them
+// into `host_mv` (2 * nt doubles, PINNED: mean then variance) behind it; fetch waits for that stream.  The handle must
+// hold its inverse quantities (cugp_has_inverse), or enqueue evaluates them first like cugp_predict.
+int cugp_predict_enqueue(cugp_gp* gp, const double* Xt, int nt, double* host_mv);
+int cugp_predict_fetch(cugp_gp* gp);
 }  // extern "C"
