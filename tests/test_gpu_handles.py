@@ -327,3 +327,25 @@ def test_forward_substitution_in_a_group(gp_mod):
         e.set_loghyperparam(HP)
         assert e.compute_loglikelihood() == vals[1][k], k               # alone (same padded size): the same bits
     b.close()
+
+
+def test_bcm_prediction_right_after_new_hyperparameters(gp_mod, oracle):
+    """BCM::compute_BCM_test_means_and_var (BCM.cpp:64-83) right after set_BCM_log_hyperparam (:123-130): the experts'
+    inverse quantities are stale, and since round 5 ONE evaluation of the whole model brings them up to date (not one
+    evaluation per expert inside cugp_predict); every expert's prediction is then in flight before the first is read.
+    The same numbers as a prediction that follows an explicit evaluation, bit for bit, and the oracle's product of
+    experts to 1e-8."""
+    X, y = synth(5 * 300 + 17, d=6, seed=21)
+    Xt = X[:33] * 0.5 + 0.1
+    b = gp_mod.BCM.split(X, y, 5)
+    b.set_BCM_log_hyperparam(HP)
+    b.loglik_grad()
+    m0, v0 = b.compute_BCM_test_means_and_var(Xt)
+    b.set_BCM_log_hyperparam(HP + 0.3)
+    b.compute_BCM_test_means_and_var(Xt)                     # stale -> grouped evaluation inside
+    b.set_BCM_log_hyperparam(HP)
+    m1, v1 = b.compute_BCM_test_means_and_var(Xt)            # stale again
+    assert np.array_equal(m0, m1) and np.array_equal(v0, v1)
+    mo, vo = oracle.bcm(X, y, 5, HP).predict(Xt)
+    assert np.allclose(m1, mo, rtol=1e-8, atol=1e-8) and np.allclose(v1, vo, rtol=1e-8, atol=1e-8)
+    b.close()
