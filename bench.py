@@ -54,8 +54,27 @@ N_METRIC, D_METRIC = 8192, 10
 HP0 = np.array([np.log(3.0), 0.0, np.log(0.1)])      # non-degenerate point: K is dense, cond ~ 1e3
 MFMA_F64_PEAK_TFLOPS = 78.6                          # MI355X dense fp64 matrix peak (spec)
 HBM_PEAK_GBS = 8000.0                                # MI355X HBM3E (MI355X_MICROARCH.md)
-ROUND = "r05"
-PMC_SUMMARY = "profiles/%s_pmc_summary.json" % ROUND        # rocprofv3 --pmc passes of this command (tools/pmc.sh)
+
+
+def pmc_summary_for(build_id):
+    """The committed counter summary (profiles/<tag>_pmc_summary.json: rocprofv3 --pmc passes of this command,
+    tools/make_profiles.sh) that was measured on THIS library: its `build_id` is the hash of the sources the library was
+    built from (cugp_build_id).  -> (tag, relative path, kernels dict) or (None, None, reason)."""
+    import glob
+    seen = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")), reverse=True):
+        try:
+            with open(f) as fh:
+                d = json.load(fh)
+        except Exception:
+            continue
+        seen.append("%s: %s" % (os.path.basename(f), d.get("build_id")))
+        if d.get("build_id") == build_id:
+            return os.path.basename(f)[:-len("_pmc_summary.json")], os.path.relpath(f, ROOT), d["kernels"]
+    return None, None, ("no committed counter summary was measured on the loaded library (build id %s; summaries: %s): "
+                        "run tools/make_profiles.sh <tag> on the GPU box and commit profiles/<tag>_pmc_summary.json"
+                        % (build_id, "; ".join(seen) or "none"))
+
 # kernels timed by the library (cugp_get_kernel_stats_kind): name as rocprofv3 prints it, what it is, and one launch in
 # how many is timed at profiling level 2 (the isolated pass; the profiled pass runs level 3: every launch)
 KINDS = {0: ("k_syrk_step", "Cholesky near-window trailing update + next diagonal block, K=128 per launch", 16),
@@ -77,17 +96,44 @@ def synth(n, d, seed):
     return np.ascontiguousarray(X), np.ascontiguousarray(y)
 
 
+def host_cpu():
+    """(model string of the host CPU, logical cores of the box)"""
+    model = None
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return model, os.cpu_count()
+
+
 def cpu_baseline(n_sample, n_full, d):
-    """Oracle (reported baseline only): LL + gradient, 1 thread, first n_sample rows of the workload."""
+    """Oracle (reported baseline only): LL + gradient, 1 thread PINNED to one core, first
+    n_sample rows of the workload; the host CPU and its core count are reported next to the number."""
     from oracle.oracle_py import Oracle
     o = Oracle()
     X, y = synth(n_full, d, 15618)
     X, y = np.ascontiguousarray(X[:n_sample]), np.ascontiguousarray(y[:n_sample])
-    t0 = time.perf_counter()
-    ll = o.loglik(X, y, HP0)
-    t1 = time.perf_counter()
-    g = o.grad(X, y, HP0)
-    t2 = time.perf_counter()
+    model, ncores = host_cpu()
+    allowed, pinned = None, None
+    try:                                              # one core of the set this process may run on (the last: away from
+        allowed = os.sched_getaffinity(0)             # the cores the runtime's helper threads were started on)
+        pinned = max(allowed)
+        os.sched_setaffinity(0, {pinned})
+    except (AttributeError, OSError):
+        pinned = None
+    try:
+        t0 = time.perf_counter()
+        ll = o.loglik(X, y, HP0)
+        t1 = time.perf_counter()
+        g = o.grad(X, y, HP0)
+        t2 = time.perf_counter()
+    finally:
+        if allowed is not None and pinned is not None:
+            os.sched_setaffinity(0, allowed)
     sec = t2 - t0
     scale = (n_full / n_sample) ** 3                  # flop-proportional; flatters the CPU (its measured exponent is >3)
     ref_s = None                                      # the reference compiled unmodified, full size, build container
@@ -100,6 +146,8 @@ def cpu_baseline(n_sample, n_full, d):
         ref_s = None
     return {
         "value": 1.0 / (sec * scale), "unit": "evals/s", "cores": 1, "kind": "port",
+        "host_cpu": model, "host_cores_total": ncores, "pinned_core": pinned,
+        "cores_allowed": len(allowed) if allowed is not None else None,
         "sample": "LL+grad on the first %d rows of the same synthetic workload: %.2f s (LL %.2f s, grad %.2f s); "
                   "scaled to N=%d by (N/n)^3" % (n_sample, sec, t1 - t0, t2 - t1, n_full),
         "ll_sample": ll, "grad_sample": [float(v) for v in g],
@@ -189,6 +237,7 @@ def main():
     if args.rehearse_rccl and world == 1:
         assert bcm._on_device
         bcm._allreduce = lambda t: (dist.all_reduce(t, op=dist.ReduceOp.SUM), t)[1]    # the collective, at one rank
+        bcm._allgather = lambda o, m: (dist.all_gather_into_tensor(o, m), o)[1]
     if not bcm.local and strong and K < world:
         pass                                          # more ranks than experts: this rank only takes part in the collectives
     passes = [p for p in args.passes.split(",") if p]
@@ -213,6 +262,7 @@ def main():
         for i in range(nwarm):
             step(i)
         fence()
+        bcm.reset_timers()
         t0_ = time.perf_counter()
         r_ = (float("nan"), np.full(3, np.nan), None)
         for i in range(nsteps):
@@ -230,8 +280,16 @@ def main():
 
     # ---- pass 1, timed: the default path, nothing instrumented -> `value`
     dt, ll, g = float("nan"), float("nan"), np.full(3, np.nan)
+    exchange = None
     if "timed" in passes:
         dt, ll, g = timed_steps(args.warmup, args.steps)
+        # this rank's split of an evaluation on the host clock: its experts (enqueue -> rows in device memory), the
+        # exchange (collective + read-back into pinned memory + synchronise), and what is left (hyper-parameter
+        # update, Python) -- the record a rehearsal of one rank of an 8-GPU run is read from
+        exchange = {"form": bcm.exchange_form, "backend": args.backend if collective else None,
+                    "ranks_in_group": world if collective else 0,
+                    "device_ms": 1e3 * bcm.t_device / args.steps, "collective_ms": 1e3 * bcm.t_collective / args.steps,
+                    "host_between_evaluations_ms": 1e3 * (dt - bcm.t_device - bcm.t_collective) / args.steps}
 
     # ---- pass 2, profiled: the same evaluations with HIP events around the MFMA launches -> roofline*
     timed_launches = can_profile and "profiled" in passes
@@ -323,6 +381,7 @@ def main():
                             comm_device=torch.device("cuda", local_rank) if args.rehearse_rccl else None)
             if args.rehearse_rccl and world == 1:
                 sb._allreduce = lambda t: (dist.all_reduce(t, op=dist.ReduceOp.SUM), t)[1]
+                sb._allgather = lambda o, m: (dist.all_gather_into_tensor(o, m), o)[1]
             for i in range(2):
                 sb.set_loghyper(HP0 + 1e-3 * i)
                 sb.loglik_grad()
@@ -377,18 +436,25 @@ def main():
             "ms_per_step_profiled": (1e3 * dt_prof / args.steps) if dt_prof else None,
             "ll_last": ll, "grad_last": [float(v) for v in g],
         }
+        if exchange:
+            out["exchange"] = exchange
         if predict:
             out["predict"] = predict
         out.update(subs)
         # HBM bytes per launch from the rocprofv3 --pmc passes of this same command, committed under profiles/
-        # (tools/pmc.sh, tools/pmc_summary.py: 2 x FETCH_SIZE + WRITE_SIZE per launch; counters cannot be read
-        # in-process, so the figure is a committed measurement and says where it comes from)
-        pmc = {}
-        try:
-            with open(os.path.join(ROOT, PMC_SUMMARY)) as f:
-                pmc = json.load(f)["kernels"] if args.n == N_METRIC else {}
-        except Exception:
-            pmc = {}
+        # (tools/make_profiles.sh, tools/pmc_summary.py: 2 x FETCH_SIZE + WRITE_SIZE per launch; counters cannot be
+        # read in-process, so the figure is a committed measurement).  It is only reported when it was measured on the
+        # library that is loaded now: the summary carries the hash of the sources it was built from (cugp_build_id);
+        # otherwise traffic is null and traffic_source says why.
+        from cugp_amd import capi as _capi
+        build_id = (_capi.lib().cugp_build_id() or b"unknown").decode()
+        out["library_build_id"] = build_id
+        ROUND, PMC_SUMMARY, pmc = pmc_summary_for(build_id)
+        pmc_reason = None
+        if ROUND is None:
+            pmc_reason, pmc = pmc, {}
+        elif args.n != N_METRIC:
+            pmc_reason, pmc = "counter summary is of the N=%d workload" % N_METRIC, {}
 
         def dur(st):
             # level 5: from the end of the launch in front of it on its stream (where rocprofv3 puts an in-order
@@ -401,7 +467,7 @@ def main():
             r = {"kernel": "%s (%s; fp64 MFMA 16x16x4)" % (name, what), "bound": "mfma", "achieved": ach,
                  "peak": MFMA_F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_F64_PEAK_TFLOPS,
                  "traffic": pmc.get(name, {}).get("hbm_bytes_per_launch"),
-                 "traffic_source": PMC_SUMMARY if name in pmc else None,
+                 "traffic_source": PMC_SUMMARY if name in pmc else (pmc_reason or "kernel not in %s" % PMC_SUMMARY),
                  "mfma_busy_frac_pmc": pmc.get(name, {}).get("mfma_busy_frac"),
                  "launches_timed": int(st["launches"]), "timed_one_launch_in": 1,
                  "avg_launch_us": 1e3 * dur(st) / st["launches"],
@@ -423,10 +489,10 @@ def main():
             out["roofline"] = dict(recs[dom])
             out["roofline"]["dominant_by"] = ("largest share of the MFMA kernels' time in the profiled pass "
                                               "(est_ms_per_eval); rocprofv3 --kernel-trace --stats of that pass alone "
-                                              "(bench.py --passes profiled): profiles/%s_bench_profiled_n8192_kernel_stats.csv, "
-                                              "of the timed pass: profiles/%s_bench_timed_n8192_kernel_stats.csv, of the "
-                                              "isolated pass: profiles/%s_bench_isolated_n8192_kernel_stats.csv"
-                                              % (ROUND, ROUND, ROUND))
+                                              "(bench.py --passes profiled): profiles/<tag>_bench_profiled_n8192_kernel_stats.csv, "
+                                              "of the timed pass: profiles/<tag>_bench_timed_n8192_kernel_stats.csv, of the "
+                                              "isolated pass: profiles/<tag>_bench_isolated_n8192_kernel_stats.csv; <tag> = "
+                                              + (ROUND or "(none measured on this library yet)"))
             out["roofline"]["note"] = ("achieved/frac: profiled pass = the timed pass's schedule with every launch timed "
                                        "(profiling level %d: 5 = by its own workgroups' first start / last end, nothing added "
                                        "to the streams), where a launch shares the CUs with kernels on the other streams; "
@@ -457,15 +523,14 @@ def main():
             out["roofline_kbuild"] = {"kernel": "k_build (SE covariance, lower tiles)", "bound": "hbm", "achieved": gbs,
                                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                                       "traffic": pmc.get("k_build", {}).get("hbm_bytes_per_launch"),
-                                      "traffic_source": PMC_SUMMARY if "k_build" in pmc else None,
+                                      "traffic_source": PMC_SUMMARY if "k_build" in pmc else (pmc_reason or "kernel not in %s" % PMC_SUMMARY),
                                       "launch_us": 1e3 * kb_ms, "algorithmic_bytes": nbytes,
                                       "valu_issue_frac_pmc": pmc.get("k_build", {}).get("valu_issue_frac"),
-                                      "note": "bound by VALU issue, not by HBM or its stores: 52.3 M wave64 vector instructions per "
-                                              "launch (1583 per wave: per matrix entry 30 fp64 ops of the squared distance, "
-                                              "contraction off to match the reference bit for bit, and ~65 of the library exp) x 4 "
-                                              "cycles / 1024 SIMDs = 204 k of the launch's 234 k cycles (87 %); 0.26 M store "
-                                              "instructions, no store-FIFO stalls (profiles/r05_pmc_summary.json, rocprofv3 --pmc "
-                                              "SQ_INSTS_VALU ... SQ_VMEM_WR_TA_DATA_FIFO_FULL)"}
+                                      "valu_per_wave_pmc": pmc.get("k_build", {}).get("valu_per_wave"),
+                                      "note": "bound by VALU issue, not by HBM or its stores (valu_issue_frac_pmc = wave64 vector "
+                                              "instructions x 4 cycles / 1024 SIMDs over the launch's cycles; per matrix entry 30 fp64 "
+                                              "ops of the squared distance, contraction off to match the reference bit for bit, plus "
+                                              "the exponential): rocprofv3 --pmc SQ_INSTS_VALU ... SQ_VMEM_WR_TA_DATA_FIFO_FULL"}
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, args.n), args.n, args.d)
         print(json.dumps(out), flush=True)

@@ -12,6 +12,7 @@ single-process loop of distributed_gp/BCM.cpp:153-198 whatever the number of ran
 The per-expert evaluator is injectable (`expert_factory`) so the sharding / reduction logic can be
 exercised on CPU ranks in the tests; the default builds `cugp_amd.gp.Covsum` handles on the GPU.
 """
+import os
 import time
 
 import numpy as np
@@ -30,6 +31,16 @@ def split_rows(N, K):
     """BCM::BCM row partition (BCM.cpp:85-110): floor(N/K) rows each, remainder to the last."""
     part = N // K
     return [(k * part, part if k < K - 1 else N - part * (K - 1)) for k in range(K)]
+
+
+def gather_rows_per_rank(K, world):
+    """Row slots every rank contributes to the all-gather: ceil(K / W) (ranks with fewer experts leave zeros)."""
+    return -(-K // world) if world > 0 else K
+
+
+def gather_row_index(k, world, per):
+    """Row of expert k in the gathered [W * per, 4] tensor: rank k mod W owns it as its (k // W)-th expert."""
+    return expert_owner(k, world) * per + k // world
 
 
 def _default_factory(n, d, device):
@@ -86,6 +97,50 @@ class ShardedBCM:
             self._group = _gp.BCM([X.shape[0]], X.shape[1], device)
             self._group.set_expert_data(0, X, y)
             self.local = {self.mine[0]: self._group.expert(0)}
+        # Lean exchange (round 6): the library writes this rank's rows into a compact [per, 4] device tensor, ONE
+        # all-gather moves them (no zero rows, no staging copy: all_reduce is in place, so the reduce form needs a fresh
+        # copy of the send buffer every evaluation), the result is copied into PINNED memory without blocking and one
+        # stream synchronise ends the evaluation.  Rank r owns experts r, r + W, ...: `per` = ceil(K / W) row slots per
+        # rank, unused ones stay zero.  CUGP_BCM_EXCHANGE=allreduce selects the round-5 form (A/B runs).
+        # (The CPU / gloo path takes the same all-gather with host tensors, so the world-size-2 CPU test covers its layout.)
+        self._per = gather_rows_per_rank(self.K, world)
+        # Exchange forms (CUGP_BCM_EXCHANGE overrides; all give the same bits):
+        #   library    the whole exchange inside libcugp (csrc/comm.cpp): ncclAllGather on the evaluation's own stream
+        #              directly behind its last kernel, copy into pinned memory behind that, ONE host wait -- no host
+        #              round trip between evaluation and collective, no torch ops.  Default where the rows are on the
+        #              device and the process group is RCCL (or there is one rank).
+        #   allgather  the same gather through torch.distributed (gloo on the CPU; device tensors moved by gloo in tests)
+        #   allreduce  rounds 1-5: K x 4 zero-padded rows, staging copy + all_reduce + blocking copy back
+        backend = dist.get_backend(group) if (world > 1 or (dist.is_available() and dist.is_initialized())) else None
+        form = os.environ.get("CUGP_BCM_EXCHANGE", "")
+        if not form:
+            form = "library" if (comm_device.type == "cuda" and expert_factory is None and (world == 1 or backend == "nccl")) else "allgather"
+        self.exchange_form = form
+        self._comm = None
+        if form == "library":
+            # rank 0's id reaches the other ranks through the process group that already exists
+            idt = torch.zeros(_gp.Comm.ID_BYTES, dtype=torch.uint8)
+            rehearse = world == 1 and backend == "nccl"           # one rank, but go through a real communicator
+            if world > 1 or rehearse:
+                if rank == 0:
+                    idt = torch.frombuffer(bytearray(_gp.Comm.unique_id()), dtype=torch.uint8).clone()
+                if world > 1:
+                    idt = idt.to(comm_device if backend == "nccl" else "cpu")
+                    dist.broadcast(idt, src=0, group=group)
+                uid = bytes(idt.cpu().numpy().tobytes())
+            else:
+                uid = None
+            self._comm = _gp.Comm(uid, rank, world, device)
+        self._lean = form == "allgather"
+        if self._lean:
+            self._mine_dev = torch.zeros((self._per, 4), dtype=torch.float64, device=comm_device)
+            self._all_dev = torch.zeros((world * self._per, 4), dtype=torch.float64, device=comm_device)
+            self._slots = list(range(len(self.mine)))               # expert mine[i] -> row i of _mine_dev
+            if comm_device.type == "cuda":
+                self._all_host = torch.zeros((world * self._per, 4), dtype=torch.float64).pin_memory()
+                torch.cuda.current_stream(comm_device).synchronize()
+            else:
+                self._all_host = self._all_dev
 
     # BCM::set_BCM_log_hyperparam (BCM.cpp:123-130): every expert gets the same vector
     def set_loghyper(self, hp):
@@ -101,12 +156,45 @@ class ShardedBCM:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
+    def _allgather(self, out, mine):
+        if self.world > 1:
+            dist.all_gather_into_tensor(out, mine, group=self.group)
+        else:
+            out.copy_(mine)
+        return out
+
     def reset_timers(self):
         self.t_device = self.t_collective = 0.0
 
     def loglik_grad(self):
         """-> (sum_k LL_k, sum_k grad_k, per-expert LL[K]); one collective of K x 4 doubles."""
         t0 = time.perf_counter()
+        if self._comm is not None:
+            # (device and collective time are not separable on the host clock here: they are one stream sequence;
+            #  t_collective keeps what the host spends beyond the call)
+            g = self._comm.loglik_grad_allgather(self._group, self._per)
+            t1 = time.perf_counter()
+            out = np.stack([g[gather_row_index(k, self.world, self._per)] for k in range(self.K)]) if self.K else np.zeros((0, 4))
+            self.t_device += t1 - t0
+            self.t_collective += time.perf_counter() - t1
+            return self._ordered_sum(out)
+        if self._lean:
+            if self._on_device:
+                self._group.loglik_grad_rows_device(self._mine_dev.data_ptr(), self._slots)   # returns with the rows in place
+            else:
+                rows = self._local_rows()
+                if len(self.mine):
+                    self._mine_dev[:len(self.mine)].copy_(torch.from_numpy(rows[self.mine]))
+            t1 = time.perf_counter()
+            self._allgather(self._all_dev, self._mine_dev)
+            if self._all_host is not self._all_dev:
+                self._all_host.copy_(self._all_dev, non_blocking=True)
+                torch.cuda.current_stream(self.comm_device).synchronize()
+            g = self._all_host.numpy()
+            out = np.stack([g[gather_row_index(k, self.world, self._per)] for k in range(self.K)]) if self.K else np.zeros((0, 4))
+            self.t_device += t1 - t0
+            self.t_collective += time.perf_counter() - t1
+            return self._ordered_sum(out)
         if self._on_device:
             # _send: zero everywhere except this rank's rows, which every evaluation overwrites (the other ranks' rows
             # must be exact zeros in the sum); the collective works on a copy, so nothing has to be cleared or waited
@@ -118,6 +206,16 @@ class ShardedBCM:
             self.t_device += t1 - t0
             self.t_collective += time.perf_counter() - t1
             return self._ordered_sum(out)
+        rows = self._local_rows()
+        t1 = time.perf_counter()
+        self._rows.copy_(torch.from_numpy(rows))
+        out = self._allreduce(self._rows).cpu().numpy()
+        self.t_device += t1 - t0
+        self.t_collective += time.perf_counter() - t1
+        return self._ordered_sum(out)
+
+    def _local_rows(self):
+        """[K, 4] host rows: this rank's experts' (LL, gradient), zeros elsewhere."""
         rows = np.zeros((self.K, 4))
         if self._group is not None:
             rows[self.mine] = self._group.loglik_grad_rows()
@@ -128,12 +226,7 @@ class ShardedBCM:
                 ll, g = self.local[k].fetch()
                 rows[k, 0] = ll
                 rows[k, 1:] = g
-        t1 = time.perf_counter()
-        self._rows.copy_(torch.from_numpy(rows))
-        out = self._allreduce(self._rows).cpu().numpy()
-        self.t_device += t1 - t0
-        self.t_collective += time.perf_counter() - t1
-        return self._ordered_sum(out)
+        return rows
 
     def _ordered_sum(self, out):
         ll, g = 0.0, np.zeros(3)
@@ -179,3 +272,6 @@ class ShardedBCM:
         if self._group is not None:
             self._group.close()
             self._group = None
+        if getattr(self, "_comm", None) is not None:
+            self._comm.close()
+            self._comm = None

@@ -33,6 +33,7 @@ class CugpError(RuntimeError):
 # name -> (restype, argtypes); every symbol include/cugp.h declares
 SIGNATURES = {
     "cugp_version": (C.c_int, []),
+    "cugp_build_id": (C.c_char_p, []),
     "cugp_last_error": (C.c_char_p, []),
     "cugp_device_count": (C.c_int, [_ip]),
     "cugp_create": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
@@ -87,6 +88,10 @@ SIGNATURES = {
     "cugp_bcm_loglik_grad": (C.c_int, [C.c_void_p, _dp, _dp, _dp]),
     "cugp_bcm_loglik_grad_rows": (C.c_int, [C.c_void_p, _dp]),
     "cugp_bcm_loglik_grad_rows_device": (C.c_int, [C.c_void_p, C.c_void_p, _ip]),
+    "cugp_comm_unique_id": (C.c_int, [C.c_void_p, C.c_int]),
+    "cugp_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "cugp_comm_destroy": (C.c_int, [C.c_void_p]),
+    "cugp_bcm_loglik_grad_allgather": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, _dp]),
     "cugp_bcm_predict_partial": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _dp]),
     "cugp_poe_finish": (C.c_int, [_dp, _dp, C.c_int, _dp, _dp]),
     "cugp_bcm_predict": (C.c_int, [C.c_void_p, _dp, C.c_int, _dp, _dp]),
@@ -99,6 +104,7 @@ SIGNATURES = {
     "cugp_bench_la": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _dp]),
     "cugp_bench_la_check": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _dp, _dp]),
     "cugp_potrf_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, _ip]),
+    "cugp_potrf_plan_sub": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _ip]),
 }
 
 _lib = None

@@ -280,6 +280,53 @@ int cugp_bcm_loglik_grad_rows_device(cugp_bcm* b, double* dev_rows, const int* s
     return CUGP_OK;
 }
 
+// The two halves of cugp_bcm_loglik_grad_allgather (comm.cpp) on the BCM's side.  enqueue: all experts in flight, their
+// rows {LL, g} packed into dsend[i][4] (local order) BEHIND the evaluation on ITS stream, which is returned -- whatever
+// the caller enqueues there next (the collective, the copy to the host) needs no host wait in between.  finish: waits
+// for that stream and closes the evaluation (results into the handles, status word checked).
+int cugp_bcm_enqueue_rows_packed(cugp_bcm* b, double* dsend, void** stream)
+{
+    if (!b || !dsend || !stream) return CUGP_ERR_INVALID;
+    if (b->sets.size() != 1) return CUGP_ERR_INVALID;
+    int rc = bcm_enqueue_all(b);
+    if (rc) return rc;
+    DeviceSet& ds = b->sets[0];
+    const size_t n = ds.idx.size();
+    if (ds.grouped_now) {
+        const double* dout = nullptr;
+        if ((rc = cugp_group_device_results(ds.group, &dout, stream)) ||
+            (rc = cugp_pack_result_rows(dsend, dout, (int)n, *stream))) { bcm_drain(b); return rc; }
+        return CUGP_OK;
+    }
+    // experts on streams of their own: every row behind its expert's evaluation; all but the first are waited for
+    // here, so that what follows on the first expert's stream finds every row in place
+    for (size_t i = 0; i < n; i++)
+        if ((rc = cugp_copy_result_row(b->experts[ds.idx[i]], dsend + 4 * i))) { bcm_drain(b); return rc; }
+    for (size_t i = 1; i < n; i++) {
+        double l, g3[3];
+        if ((rc = cugp_loglik_grad_fetch(b->experts[ds.idx[i]], &l, g3))) { bcm_drain(b); return rc; }
+    }
+    *stream = cugp_get_stream(b->experts[ds.idx[0]]);
+    return CUGP_OK;
+}
+
+int cugp_bcm_finish_rows(cugp_bcm* b)
+{
+    if (!b || b->sets.size() != 1) return CUGP_ERR_INVALID;
+    DeviceSet& ds = b->sets[0];
+    int rc;
+    if (ds.grouped_now) {
+        std::vector<double> lk(ds.idx.size()), gk3(3 * ds.idx.size());
+        rc = cugp_group_fetch(ds.group, lk.data(), gk3.data());
+        ds.grouped_now = false;
+        if (rc) bcm_drain(b);
+        return rc;
+    }
+    double l, g3[3];
+    if ((rc = cugp_loglik_grad_fetch(b->experts[ds.idx[0]], &l, g3))) bcm_drain(b);
+    return rc;
+}
+
 int cugp_bcm_loglik_grad(cugp_bcm* b, double* ll, double g[3], double* per_expert_ll)
 {
     if (!b) return CUGP_ERR_INVALID;

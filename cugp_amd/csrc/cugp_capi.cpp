@@ -73,6 +73,7 @@ struct GroupCtx {
     double* dout = nullptr;         // results [k][8] on the device ...
     double* hout = nullptr;         // ... and pinned
     bool overlap = false;           // hand the group's inverse blocks to the lead expert's other streams
+    int gcap = 0;                   // barrier workgroups per expert of ONE batched k_trtri_block launch (the experts' smallest share; halved with the overlap)
 };
 
 struct cugp_gp {
@@ -115,6 +116,7 @@ struct cugp_gp {
     bool tune_own[TUNE_COUNT] = {};
     unsigned cfg_epoch = 1;        // bumped when a launch shape of this handle changed: captured graphs carry launch shapes
     bool counted = false;          // this handle is in g_live[device] (the budget of barrier grids, barrier_cap)
+    int bar_quota = -1;            // barrier workgroups reserved for this handle from the device's pool; < 0: not yet asked for
     double last_ll = NAN, last_g[3] = {NAN, NAN, NAN}, last_quad = NAN, last_logdet = NAN;
     // profiling
     int prof = 0;
@@ -218,6 +220,20 @@ void tune_defaults_locked()
 {
     if (!g_tune_default_init) {
         for (int k = 0; k < TUNE_COUNT; k++) g_tune_default[k] = g_tune_init[k];
+        // CUGP_TUNE="key=value,key=value": process defaults from the environment (A/B runs of whole test suites)
+        if (const char* e = getenv("CUGP_TUNE")) {
+            while (*e) {
+                char* end = nullptr;
+                const long k = strtol(e, &end, 10);
+                if (end == e || *end != '=') break;
+                e = end + 1;
+                const long v = strtol(e, &end, 10);
+                if (end == e) break;
+                if (k >= 0 && k < TUNE_COUNT) g_tune_default[k] = (int)v;
+                e = *end == ',' ? end + 1 : end;
+                if (*end != ',' ) break;
+            }
+        }
         g_tune_default_init = true;
     }
 }
@@ -249,20 +265,46 @@ struct TuneScope {
 // resident at once.  One launch is safe by construction (G <= 64, far below the 512 slots; workgroups of a launch are
 // dispatched in order), but launches of DIFFERENT handles interleave on the device: 9 handles x 64 workgroups exceed the
 // slots, every launch is partly resident and each waits for workgroups that cannot be dispatched (a stall of seconds,
-// then NaN results).  So the handles of a device share a budget of 384 barrier workgroups: each launch takes at most
-// 384 / (live handles on the device) -- 64 up to 6 handles, 16 at 24 -- and beyond 24 live handles the block's inverse
-// goes launch by launch (k_trtri_diag + k_trtri_level), which waits for nothing.  Stalled launches then hold fewer
-// than 384 of the 512 slots whatever the interleaving, so some launch always gets the workgroups it is missing.
+// then NaN results).  So the handles of a device share a pool of 384 barrier workgroups, and a handle's share is
+// RESERVED: taken from the pool at the handle's first barrier launch -- 384 / (live handles on the device at that
+// moment), at most 64, at most what is left -- kept unchanged for the handle's lifetime and returned when it is destroyed.
+// A fixed share is what a captured graph may bake in: graphs captured while few handles were alive keep their grids, and
+// handles created later get what is left of the pool (none: their block inverses go launch by launch, k_trtri_diag +
+// k_trtri_level, which wait for nothing -- the same bits).  A handle whose inverse blocks run beside its factorisation can
+// have TWO barrier launches in flight (the block in front of the last on aux2, the last block's on the main stream):
+// each takes half the share.  The sum over everything in flight therefore stays <= 384 of the 512 slots whatever the
+// interleaving, so some launch always gets the workgroups it is missing.
 // (Per process: handles of other processes on the same GPU are not seen.)
+constexpr int BARRIER_POOL = 384;
 std::atomic<int> g_live[64];
-int barrier_cap(const cugp_gp* g)
+std::atomic<int> g_bar_used[64];
+int barrier_share(cugp_gp* g)
 {
+    if (g->bar_quota >= 0) return g->bar_quota;
     const int dev = g->device >= 0 && g->device < 64 ? g->device : 63;
     int live = g_live[dev].load(std::memory_order_relaxed);
     if (live < 1) live = 1;
-    if (live > 24) return 0;
-    const int cap = 384 / live;
-    return cap > TRTRI_BLOCK_MAXWG ? TRTRI_BLOCK_MAXWG : cap;
+    int want = live > 24 ? 0 : BARRIER_POOL / live;
+    if (want > TRTRI_BLOCK_MAXWG) want = TRTRI_BLOCK_MAXWG;
+    int used = g_bar_used[dev].load(std::memory_order_relaxed), grant;
+    do {
+        grant = want < BARRIER_POOL - used ? want : BARRIER_POOL - used;
+        if (grant < 8) grant = 0;                              // (not worth a barrier grid: launch by launch)
+    } while (grant > 0 && !g_bar_used[dev].compare_exchange_weak(used, used + grant, std::memory_order_relaxed));
+    g->bar_quota = grant;
+    return grant;
+}
+void barrier_release(cugp_gp* g)
+{
+    if (g->bar_quota > 0) g_bar_used[g->device >= 0 && g->device < 64 ? g->device : 63].fetch_sub(g->bar_quota, std::memory_order_relaxed);
+    g->bar_quota = -1;
+}
+// workgroups ONE barrier launch of this handle may hold; 0: none (launch by launch)
+int barrier_cap(cugp_gp* g)
+{
+    if (g->grp) return g->grp->gcap;                           // (the group's: cugp_group_enqueue)
+    const int share = barrier_share(g);
+    return g->overlap && share >= 16 ? share / 2 : share;
 }
 
 // block rows per hand-over to the other streams: about a sixteenth of the matrix, at least 2 tiles (interleaved
@@ -538,7 +580,8 @@ int fork_inverse_block(cugp_gp* g, int a, int b, int idx, bool before_last)
 struct StepPlan {
     int wide_k0, wide_kw;      // k tiles of the wide update issued at this step (after its panel solve) ...
     int wa0, wa1;              // ... over the tile columns [wa0, wa1); empty: none
-    int wcol;                  // step launch: columns [kb+1, kb+1+wcol)
+    int wcol;                  // step launch: columns [kb+1, kb+1+wcol) ...
+    int ks;                    // ... receive the k tiles [ks, kb] in one pass (sub-panels; ks = kb: one k tile per step)
 };
 
 static int tri_tiles(int n) { return n * (n + 1) / 2; }
@@ -571,19 +614,29 @@ int far_boundary(int nt, int P, int near, int p)
     return F;
 }
 
-StepPlan plan_step(int nt, int P, int near, int kb)
+// Sub-panels (S > 1 steps, aligned from step 0; S divides P): the near window is right-looking from sub-panel to
+// sub-panel and left-looking inside one.  The step launch of a sub-panel's LAST step updates the whole window with the
+// sub-panel's S k tiles in one pass (K = 128 S: the fixed cost of a pass over a C tile -- 256 KB of C traffic, prologue,
+// dispatch -- is paid once per S steps; K = 128 ran at 45 TF/s, 256 at 55, 512 at 59); the steps before it update only
+// the column the chain needs next, with the k tiles of the sub-panel so far (K = 128 .. 128 (S - 1)).  A column inside
+// sub-panel [s0, s0 + S) has then seen every k < s0 (earlier window and wide passes) and [s0, column) (its own step).
+StepPlan plan_step(int nt, int P, int near, int kb, int S = 1)
 {
-    StepPlan sp{0, 0, 0, 0, nt - kb - 1};
-    if (P <= 1) return sp;                                            // classic: the whole trailing matrix, k = kb
-    const int p = kb / P, i = kb % P;
-    const int F = far_boundary(nt, P, near, p);
-    if (i == P - 1 && F < nt) {
-        sp.wide_k0 = p * P;
-        sp.wide_kw = P;
-        sp.wa0 = F;
-        sp.wa1 = nt;
+    StepPlan sp{0, 0, 0, 0, nt - kb - 1, kb};
+    if (S < 1 || S > SUBPANEL_MAX || (P > 1 && P % S != 0)) S = 1;
+    int F = nt;
+    if (P > 1) {
+        const int p = kb / P, i = kb % P;
+        F = far_boundary(nt, P, near, p);
+        if (i == P - 1 && F < nt) {
+            sp.wide_k0 = p * P;
+            sp.wide_kw = P;
+            sp.wa0 = F;
+            sp.wa1 = nt;
+        }
     }
-    sp.wcol = F - (kb + 1);
+    sp.ks = kb - kb % S;
+    sp.wcol = (kb % S == S - 1) ? F - (kb + 1) : 1;
     return sp;
 }
 
@@ -624,6 +677,7 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false, const unsign
     const int w = pipe_block(g, with_inverse);
     const int P = panel_width(g);
     const int near = g->tune[TUNE_NEAR_TILES];
+    const int S = g->tune[TUNE_SUBPANEL];
     hipStream_t m = g->stream;                              // the whole factorisation is ordered on the handle's stream
     int nblk = 0, done = 0;                                 // blocks forked so far, block rows handed over
     struct Fork { int a, b; };
@@ -651,7 +705,7 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false, const unsign
         const int b = kb + 1;
         const bool hand_over = w > 0 && b - done >= w;
         if (hand_over) HIPCHK(hipEventRecord(g->bev[nblk], m));
-        const StepPlan sp = plan_step(nt, P, near, kb);
+        const StepPlan sp = plan_step(nt, P, near, kb, S);
         if (sp.wa1 > sp.wa0) {
             // panel p is factored (its last panel solve is enqueued): the far columns get the panel's K = P*128 in
             // one pass, before the next panel's first step widens the near window into them
@@ -664,9 +718,9 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false, const unsign
         TimedLaunch tl(g, m, sampled(g, kb + (int)g->eval_seq, PROF_STRIDE), true);
         // (look-ahead form: plain stores -- the panel solve that follows reads the column at once, and reading
         //  freshly non-temporally stored tiles took it 50 us instead of 16)
-        launch_syrk_step(g->dA, ld, kb, nt, g->d16, g->d64, g->dlogdet, g->dtickets, m, B(g), sp.wcol,
-                         P > 1 ? g->tune[TUNE_STEP_STREAM] : 1, zf ? g->dz : nullptr, g->dw);
-        tl.done(KIND_STEP, trailing_flop(nt, kb + 1, kb + 1 + sp.wcol, 1));
+        launch_syrk_step(g->dA, ld, kb, nt, g->d16, g->d64, g->dlogdet, g->dtickets, m, B(g), sp.wcol, sp.ks,
+                         zf ? g->dz : nullptr, g->dw);
+        tl.done(KIND_STEP, trailing_flop(nt, kb + 1, kb + 1 + sp.wcol, kb + 1 - sp.ks));
         if (hand_over) {
             // The block's own 6-8 launches take the host 15-35 us.  Where a chain step is shorter than that (small
             // matrices: ~35 us per step) they are enqueued behind the WHOLE chain of the factorisation -- enqueued at
@@ -849,6 +903,15 @@ int enqueue_continue(cugp_gp* g)
     return CUGP_OK;
 }
 
+// After a synchronise that follows ANY launch sequence with k_trtri_block in it: did one of its bounded stage waits
+// run out?  (pinned status word, entry 6 of the handle's result row.)  Reads and clears it.
+bool barrier_expired(cugp_gp* g)
+{
+    if (g->hout[6] == 0.0) return false;
+    g->hout[6] = 0.0;
+    return true;
+}
+
 int fetch_eval(cugp_gp* g)
 {
     if (!g->pending) return CUGP_OK;
@@ -856,10 +919,9 @@ int fetch_eval(cugp_gp* g)
     if ((rc = use_device(g))) return rc;
     HIPCHK(hipStreamSynchronize(g->stream));
     g->pending = false;
-    if (g->hout[6] != 0.0) {
+    if (barrier_expired(g)) {
         // a bounded wait inside a kernel ran out (k_trtri_block's stage barrier): nothing of this evaluation is to be
         // trusted, and nothing of it is kept -- the next call starts from the covariance build
-        g->hout[6] = 0.0;
         g->factor_valid = g->inverse_valid = false;
         g->last_ll = g->last_quad = g->last_logdet = NAN;
         g->last_g[0] = g->last_g[1] = g->last_g[2] = NAN;
@@ -883,6 +945,11 @@ int fetch_eval(cugp_gp* g)
 extern "C" {
 
 int cugp_version(void) { return 100; }
+
+#ifndef CUGP_BUILD_ID
+#define CUGP_BUILD_ID "unknown"
+#endif
+const char* cugp_build_id(void) { return CUGP_BUILD_ID; }
 
 const char* cugp_last_error(void) { return g_err.c_str(); }
 
@@ -967,6 +1034,7 @@ int cugp_create_padded(int n, int d, int device, int npad_min, cugp_gp** out)
 int cugp_destroy(cugp_gp* g)
 {
     if (!g) return CUGP_OK;
+    barrier_release(g);
     if (g->counted) g_live[g->device >= 0 && g->device < 64 ? g->device : 63].fetch_sub(1, std::memory_order_relaxed);
     (void)hipSetDevice(g->device);
     if (g->stream) (void)hipStreamSynchronize(g->stream);
@@ -1342,7 +1410,7 @@ int la_factor_inverse(cugp_gp* g, bool inverse)
     TuneScope ts(g);
     if ((rc = enqueue_potrf(g, inverse))) return rc;
     HIPCHK(hipStreamSynchronize(g->stream));
-    if (g->hout[6] != 0.0) { g->hout[6] = 0.0; return fail(CUGP_ERR_DEVICE, "a stage barrier of k_trtri_block ran out of polls"); }
+    if (barrier_expired(g)) return fail(CUGP_ERR_DEVICE, "a stage barrier of k_trtri_block ran out of polls");
     g->factor_valid = true;
     g->inverse_valid = inverse;
     return CUGP_OK;
@@ -1387,6 +1455,7 @@ static int la_solve(int n, const double* K, const double* y, double* x, double* 
             e = hipMemcpyAsync(x, g->dalpha, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, g->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(g->stream);
         if (e != hipSuccess) rc = fail(CUGP_ERR_DEVICE, "la_solve", e);
+        else if (barrier_expired(g)) rc = fail(CUGP_ERR_DEVICE, "a stage barrier of k_trtri_block ran out of polls");
         else {
             if (quad) *quad = g->hout[4];
             if (logdet) *logdet = g->hout[5];
@@ -1479,6 +1548,7 @@ int cugp_get_kernel_stats(cugp_gp* g, double* sum_ms, long long* launches, doubl
 }
 
 void* cugp_get_stream(cugp_gp* g) { return g ? (void*)g->stream : nullptr; }
+const double* cugp_result_row_device(cugp_gp* g) { return g ? g->dout : nullptr; }
 
 // ---------------------------------------------------------------- optimiser glue
 namespace {
@@ -1574,10 +1644,19 @@ int cugp_get_handle_tuning(cugp_gp* g, int key, int* value)
 
 int cugp_potrf_plan(int nt, int P, int near, int kb, int out[5])
 {
-    if (!out || nt <= 1 || kb < 0 || kb + 1 >= nt || P < 1) return CUGP_ERR_INVALID;
-    const StepPlan sp = plan_step(nt, P, near, kb);
-    const int v[5] = {sp.wide_k0, sp.wide_kw, sp.wa0, sp.wa1, sp.wcol};
+    int v[6];
+    const int rc = cugp_potrf_plan_sub(nt, P, near, 1, kb, v);
+    if (rc || !out) return rc ? rc : CUGP_ERR_INVALID;
     for (int i = 0; i < 5; i++) out[i] = v[i];
+    return CUGP_OK;
+}
+
+int cugp_potrf_plan_sub(int nt, int P, int near, int S, int kb, int out[6])
+{
+    if (!out || nt <= 1 || kb < 0 || kb + 1 >= nt || P < 1 || S < 1) return CUGP_ERR_INVALID;
+    const StepPlan sp = plan_step(nt, P, near, kb, S);
+    const int v[6] = {sp.wide_k0, sp.wide_kw, sp.wa0, sp.wa1, sp.wcol, sp.ks};
+    for (int i = 0; i < 6; i++) out[i] = v[i];
     return CUGP_OK;
 }
 
@@ -1645,6 +1724,7 @@ int cugp_bench_la_check(int op, int n, int device, int reps, double* ms, double*
         float t = 0;
         if (e == hipSuccess) e = hipEventElapsedTime(&t, e0, e1);
         if (r > 0 && t < best) best = t;                          // first round warms up
+        if (e == hipSuccess && barrier_expired(g)) rc = fail(CUGP_ERR_DEVICE, "a stage barrier of k_trtri_block ran out of polls");
     }
     if (logdet && rc == CUGP_OK && e == hipSuccess) {
         *logdet = NAN;
@@ -1786,6 +1866,11 @@ int cugp_group_enqueue(cugp_group* gr, int want_grad)
     for (cugp_gp* e : gr->experts) e->factor_valid = e->inverse_valid = false;
     *lead->hhs = scalars(lead);
     gr->ctx.overlap = lead->tune[TUNE_GROUP_OVERLAP] != 0;
+    {   // one batched k_trtri_block launch holds count x G workgroups: G = the experts' smallest reserved share
+        int cap = TRTRI_BLOCK_MAXWG;
+        for (cugp_gp* e : gr->experts) { const int sh = barrier_share(e); if (sh < cap) cap = sh; }
+        gr->ctx.gcap = gr->ctx.overlap && cap >= 16 ? cap / 2 : cap;
+    }
     lead->grp = &gr->ctx;
     const int gi = want_grad ? 1 : 0;
     // (with the hand-over the sequence spans several streams: enqueued launch by launch, not replayed)
@@ -1858,6 +1943,18 @@ int cugp_group_fetch(cugp_group* gr, double* ll, double* g)
             e->inverse_valid = true;
         }
     }
+    return CUGP_OK;
+}
+
+int cugp_internal_fail(int code, const char* what) { return fail(code, what); }
+
+// rows [count][4] <- the first four of every 8-double result row of src, on `stream` (one 2D copy: a group's
+// results packed for a collective)
+int cugp_pack_result_rows(double* dst, const double* src, int count, void* stream)
+{
+    if (count <= 0) return CUGP_OK;
+    HIPCHK(hipMemcpy2DAsync(dst, 4 * sizeof(double), src, 8 * sizeof(double), 4 * sizeof(double), (size_t)count,
+                            hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return CUGP_OK;
 }
 

@@ -24,6 +24,15 @@ int cugp_group_fetch(cugp_group* gr, double* ll, double* g);
 int cugp_group_device_results(cugp_group* gr, const double** dout, void** stream);
 // 4 doubles device -> device on `stream` (hipStream_t); the result row of the evaluation a single expert has in flight
 int cugp_copy_device_row(double* dst, const double* src, void* stream);
+// [count][4] <- {LL, g0, g1, g2} of every [8]-double result row of src (a group's device results), one 2D copy on `stream`
+int cugp_pack_result_rows(double* dst, const double* src, int count, void* stream);
+// error text for cugp_last_error from the other translation units; returns `code`
+int cugp_internal_fail(int code, const char* what);
+// halves of cugp_bcm_loglik_grad_allgather (comm.cpp; defined in bcm.cpp)
+int cugp_bcm_enqueue_rows_packed(cugp_bcm* b, double* dsend, void** stream);
+int cugp_bcm_finish_rows(cugp_bcm* b);
+// device copy of a single expert's result row ([8] doubles, valid once its stream -- cugp_get_stream -- has run)
+const double* cugp_result_row_device(cugp_gp* gp);
 int cugp_copy_result_row(cugp_gp* gp, double* dst);
 // the handle holds L^-1, K^-1, alpha for its current data and hyper-parameters (what a prediction needs)
 int cugp_has_inverse(const cugp_gp* gp);

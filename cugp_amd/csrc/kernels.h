@@ -28,7 +28,8 @@ enum { TUNE_LAUUM_WM2_MAX = 0,   // K^-1 product: use 64x64 tiles when there are
        TUNE_STEP_QUARTER_MAX = 14, // step kernel: launches of at most this many 64x64 workgroups run ALL their tiles as quarters (chain-bound tail)
        TUNE_STREAM_PRIO = 15,    // read when a handle is created: bit 0 = the factorisation's stream at the highest priority, bit 1 = the inverse streams at the lowest (default 0: prioritised streams serialised grouped experts in round 3)
        TUNE_BARRIER_SPIN = 16,   // polls a workgroup of k_trtri_block spends at a stage barrier before it gives up (the evaluation then fails with CUGP_ERR_DEVICE instead of hanging); 0 = give up at once (test hook)
-       TUNE_CHAIN = 17,          // the factorisation's chain as one resident launch beside the off-chain launches (0 = two launches per step)
+       TUNE_SUBPANEL = 17,       // near window in sub-panels of this many steps (1, 2 or 4; must divide the panel): the step launch of a sub-panel's last step
+                                 // updates the window with K = 128*this in ONE pass over its C tiles, the steps before it only the next column (left-looking inside the sub-panel)
        TUNE_ZFUSE = 18,          // LL-only evaluations: the forward substitution L z = y inside the factorisation's launches (1) or as 2 nt launches behind it (0)
        TUNE_COUNT = 19 };
 extern const int g_tune_init[TUNE_COUNT];     // built-in defaults
@@ -92,8 +93,10 @@ int launch_trtri_block(const double* L, const double* d64, double* T, double* U,
                        double* hstat = nullptr);
 // trailing update of step kb fused with the factorisation of diagonal block kb+1 (tickets[kb] must be 0)
 // wcol > 0: only the tile columns [kb+1, kb+1+wcol) (two-speed form: the near window)
+// ks: first k tile of the pass (sub-panels: the k tiles [ks, kb], at most SUBPANEL_MAX of them); < 0: kb alone
+constexpr int SUBPANEL_MAX = 4;
 void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* d64, double* logdet_part,
-                      unsigned* tickets, hipStream_t s, Batch bt = {}, int wcol = 0, int stream_c = 1,
+                      unsigned* tickets, hipStream_t s, Batch bt = {}, int wcol = 0, int ks = -1,
                       const double* zv = nullptr, double* wv = nullptr);
                       // zv / wv (when given): nt - kb - 1 more workgroups apply w_i -= L(i,kb) z_kb to the rows below
 // wide trailing update: tile columns [ca, cb) (rows >= column) -= L(., k tiles [k0, k0+kw)) L(.)^T; returns tiles

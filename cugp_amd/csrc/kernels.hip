@@ -1677,30 +1677,33 @@ __global__ __launch_bounds__(256) void k_potf2(double* __restrict__ A, int ld, i
                d64 + (size_t)kb * 8192, logdet_part + kb, sm, red);
 }
 
-// one 16x16 micro tile of A(kb+1,kb+1) -= L(kb+1,kb) L(kb+1,kb)^T by ONE workgroup, operands straight from L2: the
-// four waves take a quarter of the k range each (8 MFMAs in two chains; one wave issues an fp64 MFMA per ~138 cycles,
-// so the whole K = 128 on one wave was 32 x 138 = 4.4k cycles of the chain), partial sums through LDS, added in a fixed
-// order by wave 0, which stores the tile write-through (the consumer is another workgroup).
-__device__ __forceinline__ void diag_update_tile(double* __restrict__ A, int ld, int kb, int mtile, double* __restrict__ part)
+// one 16x16 micro tile of A(kb+1,kb+1) -= sum_{k in [ks, kb]} L(kb+1,k) L(kb+1,k)^T by ONE workgroup, operands straight
+// from L2: the four waves take a quarter of the k range each (8 MFMAs per k tile in two chains; one wave issues an fp64
+// MFMA per ~138 cycles, so the whole K = 128 on one wave was 32 x 138 = 4.4k cycles of the chain), partial sums through
+// LDS, added in a fixed order by wave 0, which stores the tile write-through (the consumer is another workgroup).
+// NK = kb + 1 - ks k tiles (sub-panelled near window, enqueue_potrf: the tile receives the whole sub-panel so far in
+// this one pass); every operand of the wave is requested before its first MFMA.
+template <int NK>
+__device__ __forceinline__ void diag_update_tile_nk(double* __restrict__ A, int ld, int kb, int mtile, double* __restrict__ part)
 {
     const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int bi, bj;
     tri_index(mtile, bi, bj);
     const int c = lane & 15, g = lane >> 4;
-    const int k0 = kb * TILE + 32 * w, i0 = (kb + 1) * TILE;
+    const int k0 = (kb + 1 - NK) * TILE + 32 * NK * w, i0 = (kb + 1) * TILE;
     const double* Li = A + (size_t)(i0 + bi * MT + c) * ld + k0 + g;
     const double* Lj = A + (size_t)(i0 + bj * MT + c) * ld + k0 + g;
     double* C = A + (size_t)(i0 + bi * MT + g) * ld + i0 + bj * MT + c;
-    double la[8], lb[8];                                // all operands in flight before the first MFMA
+    double la[8 * NK], lb[8 * NK];                      // all operands in flight before the first MFMA
 #pragma unroll
-    for (int s = 0; s < 8; s++) { la[s] = -Li[4 * s]; lb[s] = Lj[4 * s]; }
+    for (int s = 0; s < 8 * NK; s++) { la[s] = -Li[4 * s]; lb[s] = Lj[4 * s]; }
     d4 acc = (d4){0.0, 0.0, 0.0, 0.0}, acc2 = acc;
     if (w == 0) {
 #pragma unroll
         for (int r = 0; r < 4; r++) acc[r] = C[(size_t)(4 * r) * ld];
     }
 #pragma unroll
-    for (int s = 0; s < 8; s += 2) {
+    for (int s = 0; s < 8 * NK; s += 2) {
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(la[s], lb[s], acc, 0, 0, 0);
         acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(la[s + 1], lb[s + 1], acc2, 0, 0, 0);
     }
@@ -1716,6 +1719,16 @@ __device__ __forceinline__ void diag_update_tile(double* __restrict__ A, int ld,
             const double v = ((acc[r] + part[r * 64 + lane]) + part[(4 + r) * 64 + lane]) + part[(8 + r) * 64 + lane];
             __hip_atomic_store(C + (size_t)(4 * r) * ld, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    }
+}
+
+__device__ __forceinline__ void diag_update_tile(double* __restrict__ A, int ld, int kb, int ks, int mtile, double* __restrict__ part)
+{
+    switch (kb + 1 - ks) {                              // (uniform over the launch)
+    case 1: diag_update_tile_nk<1>(A, ld, kb, mtile, part); break;
+    case 2: diag_update_tile_nk<2>(A, ld, kb, mtile, part); break;
+    case 3: diag_update_tile_nk<3>(A, ld, kb, mtile, part); break;
+    default: diag_update_tile_nk<4>(A, ld, kb, mtile, part); break;
     }
 }
 
@@ -1738,11 +1751,13 @@ static_assert(POTF2_LDS >= GEMM_LDS, "the fused step kernel sizes its LDS for bo
 // wcol (two-speed form, enqueue_potrf): the launch updates only the tile columns [kb+1, kb+1+wcol) -- the near
 // window -- and the far columns are brought up to date once per panel by k_syrk_wide with K = P*128.
 // wcol >= the trailing size: the classic full update.
+// ks (sub-panelled near window): the launch subtracts the k tiles [ks, kb] in one pass, K = (kb + 1 - ks) * 128 --
+// the columns it touches have not seen any of them yet (plan_step, cugp_capi.cpp).  ks = kb: one k tile per step.
 __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, int ld, int kb,
                                                       double* __restrict__ d16, double* __restrict__ d64,
                                                       double* __restrict__ logdet_part,
                                                       unsigned* __restrict__ tickets, int nfull, int wcol,
-                                                      int stream_c, const ExpertPtrs* __restrict__ bt,
+                                                      int ks, const ExpertPtrs* __restrict__ bt,
                                                       unsigned long long* stamp, int vec0, const double* __restrict__ zv,
                                                       double* __restrict__ wv)
 {
@@ -1765,15 +1780,11 @@ __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, in
     __shared__ double red[TILE + 4 * MT];
     __shared__ unsigned s_ticket;
     if (bid < NDIAGWG) {
-        // (timing experiments only, TUNE_CHAIN bits 0x200 / 0x100 -> stream_c bits 4 / 2: the chain without its diagonal
-        //  update / without the diagonal block's factorisation -- results are garbage, the evaluation's time says what
-        //  a faster chain could win at most)
-        if (stream_c & 4) return;
         // the factorisation's serial chain: win instruction issue over the product waves sharing the SIMD
         // (this launch's own tiles and the inverse blocks running on the other streams)
         __builtin_amdgcn_s_setprio(3);
         WGT(wgt_, WGT_DIAGUPD, kb);
-        diag_update_tile(A, ld, kb, bid, sm);
+        diag_update_tile(A, ld, kb, ks, bid, sm);
         // publish: wave 0 drains its (agent-scope, write-through) tile stores, then ONE of its lanes draws the
         // ticket (relaxed: the tile is in memory before the ticket, and the last arriver reads the tiles with
         // agent-scope loads that bypass its L1 -- the hand-off form of the CDNA guide's Guideline 16, R1)
@@ -1789,7 +1800,6 @@ __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, in
             s_ticket = __hip_atomic_fetch_add(&tickets[kb], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if (s_ticket != NDIAGWG - 1) return;           // not the last arriver
-        if (stream_c & 2) return;                      // (timing experiment, see above)
         // (the last arriver reads the 36 micro tiles with agent-scope loads: potf2_body<true>, no acquire fence)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int kn = kb + 1;
@@ -1816,7 +1826,7 @@ __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, in
         const int i0 = (kb + 1 + ti) * TILE, j0 = (kb + 1 + tj) * TILE;
         d4 acc[4][4];
         acc_zero(acc);
-        tile_nt<false>(A + (size_t)i0 * ld, ld, A + (size_t)j0 * ld, ld, kb * TILE, (kb + 1) * TILE, acc, (char*)sm);
+        tile_nt<false>(A + (size_t)i0 * ld, ld, A + (size_t)j0 * ld, ld, ks * TILE, (kb + 1) * TILE, acc, (char*)sm);
         tile_accum_store<-1>(A + (size_t)i0 * ld + j0, ld, acc);
     } else {
         int ti, tj;
@@ -1825,7 +1835,7 @@ __global__ __launch_bounds__(256, 2) void k_syrk_step(double* __restrict__ A, in
         const int i0 = (kb + 1 + ti) * TILE + ((y >> 1) & 1) * 64, j0 = (kb + 1 + tj) * TILE + (y & 1) * 64;
         d4 acc[2][2];
         acc_zero(acc);
-        tile_nt<false>(A + (size_t)i0 * ld, ld, A + (size_t)j0 * ld, ld, kb * TILE, (kb + 1) * TILE, acc, (char*)sm);
+        tile_nt<false>(A + (size_t)i0 * ld, ld, A + (size_t)j0 * ld, ld, ks * TILE, (kb + 1) * TILE, acc, (char*)sm);
         tile_accum_store<-1>(A + (size_t)i0 * ld + j0, ld, acc);
     }
 }
@@ -2272,7 +2282,7 @@ static inline unsigned long long* take_stamp() { unsigned long long* p = t_stamp
         }                                                                                           \
     } while (0)
 
-const int g_tune_init[TUNE_COUNT] = {768, 1200, 384, -1, 511, 1, 1, 1 << 20, 16, 500, 32, 1, 1, 256, 1536, 0, 1 << 21, 0, 1};   // defaults chosen by interleaved A/B runs (tools/ab.py)
+const int g_tune_init[TUNE_COUNT] = {768, 1200, 384, -1, 511, 1, 1, 1 << 20, 16, 500, 32, 1, 1, 256, 1536, 0, 1 << 21, 1, 1};   // defaults chosen by interleaved A/B runs (tools/ab.py)
 thread_local const int* t_tune = g_tune_init;
 
 static inline int tri_count(int n) { return n * (n + 1) / 2; }
@@ -2385,7 +2395,7 @@ static inline int trap_count(int m, int wcol)          // tiles (ti >= tj) of th
 }
 
 void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* d64, double* logdet_part,
-                      unsigned* tickets, hipStream_t s, Batch bt, int wcol, int stream_c, const double* zv, double* wv)
+                      unsigned* tickets, hipStream_t s, Batch bt, int wcol, int ks, const double* zv, double* wv)
 {
     const int m = nt - kb - 1;
     if (m <= 0) return;
@@ -2402,9 +2412,10 @@ void launch_syrk_step(double* A, int ld, int kb, int nt, double* d16, double* d6
     if ((long long)ntl * bt.count * 4 <= tune(TUNE_STEP_QUARTER_MAX)) nfull = 0;
     const int vec0 = NDIAGWG + nfull + 4 * (ntl - nfull);
     const unsigned nwg = vec0 + (zv ? m : 0);
-    stream_c = (stream_c ? 1 : 0) | ((tune(TUNE_CHAIN) >> 7) & 6);     // (bits 0x100, 0x200: timing experiments)
+    if (ks < 0 || ks > kb) ks = kb;
+    if (kb + 1 - ks > SUBPANEL_MAX) return;               // (plan_step never asks for more)
     CUGP_LAUNCH(k_syrk_step, bt.tab ? dim3(bt.count, nwg) : dim3(nwg), dim3(256), STEP_LDS, s, A, ld, kb, d16,
-                       d64, logdet_part, tickets, nfull, wcol, stream_c, bt.tab, take_stamp(), vec0, zv, wv);
+                       d64, logdet_part, tickets, nfull, wcol, ks, bt.tab, take_stamp(), vec0, zv, wv);
 }
 
 // tile columns [ca, cb) (rows >= column) -= L(., k0..k0+kw) L(., k0..k0+kw)^T; returns the number of tiles

@@ -218,6 +218,45 @@ class Covsum:
         return {"sum_ms": s.value, "launches": n.value, "flop": f.value, "disp_ms": dms.value}
 
 
+class Comm:
+    """The library's own RCCL communicator (cugp_comm_*, csrc/comm.cpp): one process per GPU, expert k on rank k mod W.
+    `unique_id`: the 128 bytes rank 0 got from Comm.unique_id(), handed to every rank by the caller (ShardedBCM
+    broadcasts them through torch.distributed); None with world == 1: no communicator, nothing to exchange."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_ubyte * Comm.ID_BYTES)()
+        check(capi.lib().cugp_comm_unique_id(buf, Comm.ID_BYTES))
+        return bytes(buf)
+
+    def __init__(self, unique_id, rank, world, device):
+        self.rank, self.world, self.device = int(rank), int(world), int(device)
+        self._h = C.c_void_p()
+        idbuf = (C.c_ubyte * Comm.ID_BYTES).from_buffer_copy(unique_id) if unique_id is not None else None
+        check(capi.lib().cugp_comm_create(idbuf, Comm.ID_BYTES if unique_id is not None else 0, self.rank, self.world,
+                                          self.device, C.byref(self._h)))
+
+    def loglik_grad_allgather(self, bcm, per):
+        """One sharded objective evaluation: this rank's experts (`bcm`: a BCM, or None on a rank that owns none)
+        evaluated, everybody's rows gathered -> [world * per, 4] (rank r's i-th expert in row r * per + i)."""
+        out = np.empty((self.world * int(per), 4))
+        check(capi.lib().cugp_bcm_loglik_grad_allgather(bcm._h if bcm is not None else None, self._h, int(per), ptr(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            capi.lib().cugp_comm_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class BCM:
     """Experts resident on the GPU(s) of this process (class BCM, distributed_gp/BCM.h).  `devices` lists the
     GPUs (expert k on devices[k mod len], cg_solver.cpp:93; default: the one `device`).  `BCM.split` reproduces

@@ -39,6 +39,9 @@ typedef struct cugp_gp cugp_gp;    /* one expert: Covsum / the cuda_gp.cu global
 typedef struct cugp_bcm cugp_bcm;  /* a set of experts resident on one GPU: class BCM */
 
 int cugp_version(void);
+/* hash of the sources this library was built from (cugp_amd/build.py: source_hash); measurements kept as files carry
+ * it, so a reader can tell which library they belong to (bench.py: roofline.traffic) */
+const char *cugp_build_id(void);
 const char *cugp_last_error(void);          /* thread-local text of the last failure */
 int cugp_device_count(int *count);
 
@@ -196,6 +199,23 @@ int cugp_bcm_loglik_grad_rows(cugp_bcm *b, double *rows);
 /* the same rows left in DEVICE memory for a collective that stays on the device (RCCL all-reduce): row slot[k] of
  * dev_rows ([.][4] doubles on the handle's device) receives local expert k's {LL, g}; single-device handles */
 int cugp_bcm_loglik_grad_rows_device(cugp_bcm *b, double *dev_rows, const int *slot);
+/* ---- the same exchange done by the library, one process per GPU (RCCL over xGMI) ----
+ * replaces: the master's worker-by-worker collection of log-likelihoods and gradients over TCP,
+ * cuda_scalingdist/cg_solver.cpp:72-213 (and the hyper-parameter broadcast :245-279, which is not needed: every rank
+ * runs the same deterministic optimiser on identical sums).  Expert k lives on rank k mod W (cg_solver.cpp:93).
+ * cugp_comm_unique_id: rank 0 obtains the 128-byte id and hands it to the other ranks by any means (the Python layer
+ * broadcasts it through torch.distributed, tests/cpp/rccl_driver.cpp through a file); cugp_comm_create: collective
+ * over all ranks (id == NULL with world == 1: no communicator, nothing to exchange).  RCCL is opened at run time
+ * (librccl.so.1): CUGP_ERR_NODEVICE when it cannot be.
+ * cugp_bcm_loglik_grad_allgather: evaluate this rank's experts (b; NULL on a rank that owns none) and gather
+ * everybody's rows: rows_out[world * per][4], rank r's i-th expert (global expert r + i * world) in row r * per + i as
+ * {LL, g[3]}, zeros in slots beyond a rank's experts; per >= the largest number of experts on a rank.  Evaluation,
+ * ncclAllGather and the copy to the host are one in-order sequence on the evaluation's stream: one host wait. */
+typedef struct cugp_comm cugp_comm;
+int cugp_comm_unique_id(void *id, int bytes);        /* bytes must be 128 */
+int cugp_comm_create(const void *id, int bytes, int rank, int world, int device, cugp_comm **out);
+int cugp_comm_destroy(cugp_comm *c);
+int cugp_bcm_loglik_grad_allgather(cugp_bcm *b, cugp_comm *c, int per, double *rows_out);
 int cugp_bcm_predict_partial(cugp_bcm *b, const double *Xt, int nt, double *sum_prec, double *sum_prec_mean);
 int cugp_poe_finish(const double *sum_prec, const double *sum_prec_mean, int nt, double *mean, double *var);
 int cugp_bcm_predict(cugp_bcm *b, const double *Xt, int nt, double *mean, double *var); /* BCM.cpp:64-83 */
@@ -223,6 +243,9 @@ int cugp_get_handle_tuning(cugp_gp *gp, int key, int *value);
  * tiles (pure arithmetic, no device): out = {wide k0, wide k tiles, wide columns [a0,a1), step-launch width in tile
  * columns from kb+1}; tests/test_host_logic.py replays it: every tile sees every k exactly once, ascending */
 int cugp_potrf_plan(int nt, int P, int near_tiles, int kb, int out[5]);
+/* the same with the near window in sub-panels of S steps (tuning key 17); out[5] = first k tile of the step launch's
+ * pass: it subtracts the k tiles [out[5], kb] from the columns [kb+1, kb+1+out[4]) */
+int cugp_potrf_plan_sub(int nt, int P, int near_tiles, int S, int kb, int out[6]);
 
 #ifdef __cplusplus
 }

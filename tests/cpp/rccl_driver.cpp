@@ -1,9 +1,10 @@
 // rccl_driver.cpp -- the reference's multi-process BCM driver (cuda_scalingdist/main.cpp:70-233 master/worker loop,
 // cg_solver.cpp:72-213 gathers of log-likelihood and gradient, :245-279 hyper-parameter broadcast), as a C++ host
-// would write it on libcugp + RCCL: one process per GPU, expert k on rank k mod W (cg_solver.cpp:93), and per
-// evaluation ONE ncclAllReduce of the K x 4 device-resident rows {LL_k, g_k} (zeros in the rows of other ranks),
-// summed in expert order on every rank -- no TCP, no host staging before the collective.  Prediction: per-rank
-// product-of-experts partial sums (distributed_gp/BCM.cpp:45-62), one ncclAllReduce of 2 x nt doubles, cugp_poe_finish.
+// would write it on libcugp + RCCL: one process per GPU, expert k on rank k mod W (cg_solver.cpp:93).  The objective
+// goes through the library's own exchange (cugp_comm_*, cugp_bcm_loglik_grad_allgather: evaluation, ncclAllGather of
+// every rank's {LL_k, g_k} rows and the copy to the host as ONE sequence on the evaluation's stream), summed in expert
+// order on every rank -- no TCP, no host wait before the collective.  Prediction: per-rank product-of-experts partial
+// sums (distributed_gp/BCM.cpp:45-62), one ncclAllReduce of 2 x nt doubles by the driver itself, cugp_poe_finish.
 //
 //   rccl_driver <id file> <rank> <world> <data file> <K> <rows per expert> <d> <nt> [device]
 //     id file  : rank 0 writes the ncclUniqueId there, the others wait for it (any shared path; no MPI needed)
@@ -66,22 +67,26 @@ int main(int argc, char** argv)
 
     // ---- communicator: rank 0 publishes the id through a file (stands in for the reference's TCP hand-shake) ----
     HK(hipSetDevice(device));
-    ncclUniqueId id;
+    ncclUniqueId id;                                   // the driver's own communicator (prediction) ...
+    unsigned char lid[128];                            // ... and the id of the library's (objective)
     if (rank == 0) {
         NK(ncclGetUniqueId(&id));
+        CK(cugp_comm_unique_id(lid, (int)sizeof lid));
         std::string tmp = std::string(idfile) + ".tmp";
         FILE* g = fopen(tmp.c_str(), "wb");
-        if (!g || fwrite(&id, sizeof id, 1, g) != 1) return 1;
+        if (!g || fwrite(&id, sizeof id, 1, g) != 1 || fwrite(lid, sizeof lid, 1, g) != 1) return 1;
         fclose(g);
         rename(tmp.c_str(), idfile);
     } else {
         FILE* g = nullptr;
         for (int tries = 0; tries < 600 && !(g = fopen(idfile, "rb")); tries++) std::this_thread::sleep_for(std::chrono::milliseconds(100));
-        if (!g || fread(&id, sizeof id, 1, g) != 1) { fprintf(stderr, "no id file\n"); return 1; }
+        if (!g || fread(&id, sizeof id, 1, g) != 1 || fread(lid, sizeof lid, 1, g) != 1) { fprintf(stderr, "no id file\n"); return 1; }
         fclose(g);
     }
     ncclComm_t comm;
     NK(ncclCommInitRank(&comm, world, id, rank));
+    cugp_comm* lc = nullptr;
+    CK(cugp_comm_create(lid, (int)sizeof lid, rank, world, device, &lc));
     hipStream_t cs;
     HK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
 
@@ -98,15 +103,12 @@ int main(int argc, char** argv)
         CK(cugp_bcm_set_loghyper(b, hp));
     }
 
-    // ---- objective: rows stay on the device from the evaluation's result buffer to the collective ----
-    double* drows = nullptr;
-    HK(hipMalloc((void**)&drows, (size_t)K * 4 * sizeof(double)));
-    HK(hipMemset(drows, 0, (size_t)K * 4 * sizeof(double)));                 // the other ranks' rows: exact zeros in the sum
-    if (nl > 0) CK(cugp_bcm_loglik_grad_rows_device(b, drows, mine.data())); // returns with this rank's rows in place
-    NK(ncclAllReduce(drows, drows, (size_t)K * 4, ncclDouble, ncclSum, comm, cs));
-    std::vector<double> hrows((size_t)K * 4);
-    HK(hipMemcpyAsync(hrows.data(), drows, hrows.size() * sizeof(double), hipMemcpyDeviceToHost, cs));
-    HK(hipStreamSynchronize(cs));
+    // ---- objective: evaluation, all-gather and copy to the host are one stream sequence inside the library ----
+    const int per = (K + world - 1) / world;                                // row slots per rank
+    std::vector<double> gathered((size_t)world * per * 4), hrows((size_t)K * 4);
+    CK(cugp_bcm_loglik_grad_allgather(b, lc, per, gathered.data()));
+    for (int k = 0; k < K; k++)                                              // expert k = rank (k mod W)'s (k / W)-th
+        memcpy(&hrows[4 * (size_t)k], &gathered[4 * ((size_t)(k % world) * per + k / world)], 4 * sizeof(double));
     double ll = 0.0, g[3] = {0, 0, 0};
     for (int k = 0; k < K; k++) {                                            // expert order, as BCM.cpp:161-197
         ll = ll + hrows[4 * k];
@@ -147,7 +149,8 @@ int main(int argc, char** argv)
         printf("\"ok\": 1}\n");
     }
     if (b) cugp_bcm_destroy(b);
-    (void)hipFree(drows); (void)hipFree(dpp);
+    cugp_comm_destroy(lc);
+    (void)hipFree(dpp);
     ncclCommDestroy(comm);
     return 0;
 }

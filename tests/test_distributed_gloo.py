@@ -61,6 +61,23 @@ def _worker(rank, world, port, q):
     Xt = np.vstack([X[:3], X[:5] * 0.7 - 0.1])
     m, v = b.predict(Xt)
     tr = b.cg_solve(30)
+    # an UNEVEN shard count (5 experts on 2 ranks: rank 0 owns 3, rank 1 owns 2 and leaves a zero slot in the
+    # all-gather) against the same experts summed in this process without any collective
+    K5 = 5
+    ex5 = [(X[o:o + n], y[o:o + n]) for o, n in split_rows(128, K5)]
+    b5 = ShardedBCM(ex5, rank=rank, world=world, expert_factory=OracleExpert)
+    b5.set_loghyper([1.2, 0.7, -0.3])
+    ll5, g5, per5 = b5.loglik_grad()
+    s5 = ShardedBCM(ex5, rank=0, world=1, expert_factory=OracleExpert)
+    s5.set_loghyper([1.2, 0.7, -0.3])
+    sl5, sg5, sper5 = s5.loglik_grad()
+    assert ll5 == sl5 and np.array_equal(g5, sg5) and np.array_equal(per5, sper5), (rank, ll5, sl5)
+    os.environ["CUGP_BCM_EXCHANGE"] = "allreduce"      # the round-5 exchange gives the same bits
+    b5r = ShardedBCM(ex5, rank=rank, world=world, expert_factory=OracleExpert)
+    b5r.set_loghyper([1.2, 0.7, -0.3])
+    ll5r, g5r, per5r = b5r.loglik_grad()
+    os.environ.pop("CUGP_BCM_EXCHANGE")
+    assert ll5r == sl5 and np.array_equal(g5r, sg5) and np.array_equal(per5r, sper5)
     q.put((rank, ll, g, per, m, v, b.hp.copy(), tr))
     dist.barrier()
     dist.destroy_process_group()

@@ -22,8 +22,9 @@ R2 = os.path.join(GOLDEN, "golden_r2")
 
 def job(name):
     p = os.path.join(R2, name + ".json")
-    if not os.path.exists(p):
-        pytest.skip("golden_r2/%s.json not generated (tests/golden/run_jobs.sh)" % name)
+    # a committed fixture that has gone missing is a FAILURE, not a skip: every job listed by
+    # `make_golden.py --job list` (tests/golden/run_jobs.sh) is in the tree (tests/test_oracle_golden.py checks the list)
+    assert os.path.exists(p), "golden_r2/%s.json is missing (tests/golden/run_jobs.sh generates it in the build container)" % name
     with open(p) as f:
         return json.load(f)
 
@@ -292,7 +293,13 @@ def _probes_match(tr, c, min_moving):
     moving = np.abs(tr[1:n + 1, 3] + c["final_ll"]) > 1e-9 * abs(c["final_ll"])
     assert moving.sum() >= min_moving and np.all(err[moving] <= 5e-5), (int(moving.sum()), float(np.max(err[moving])))
     assert tr.shape[0] == probes.shape[0] + 1 or not moving[-1], (tr.shape, probes.shape)   # a different length: in the flat tail only
+    # ... and bounded even there: a run half as long (or half again as long) as the reference's is a divergence, not noise
+    assert abs((tr.shape[0] - 1) - probes.shape[0]) <= max(8, probes.shape[0] // 2), (tr.shape, probes.shape)
     return err, moving
+
+
+FLAT_HP_TOL = 2e-3   # end point of a run that stopped on the flat plateau, per hyper-parameter (the plateau is flat to 1e-9
+                     # relative in f over a box of about this size; a run that ended while descending is held to 5e-5)
 
 
 def test_cg_trajectory_sine_2048(gp_mod, sine4160):
@@ -306,8 +313,8 @@ def test_cg_trajectory_sine_2048(gp_mod, sine4160):
     err, moving = _probes_match(tr, c, 20)
     print("cg_sine2048: %d probes, %d while the objective moves, max rel. deviation there %.2e" % (err.shape[0], moving.sum(), np.max(err[moving])))
     final = g.get_loghyperparam()
-    if moving[-1]:                                                           # the run ended while still descending
-        assert np.allclose(final, c["final_hp"], atol=5e-5), (final, c["final_hp"])
+    print("cg_sine2048: end point deviates by %.2e from the reference's" % np.max(np.abs(final - np.array(c["final_hp"]))))
+    assert np.allclose(final, c["final_hp"], atol=5e-5 if moving[-1] else FLAT_HP_TOL), (final, c["final_hp"])
     assert abs(g.compute_loglikelihood() - c["final_ll"]) <= 1e-7 * abs(c["final_ll"])
     g.close()
 
@@ -336,8 +343,9 @@ def test_bcm16_cg_8000(gp_mod, si24000):
     tr = b.cg_solve()
     err, moving = _probes_match(tr, c, 20)
     print("bcm16_cg_8000: %d probes, %d while the objective moves, max rel. deviation there %.2e" % (err.shape[0], moving.sum(), np.max(err[moving])))
-    if moving[-1]:
-        assert np.allclose(b.get_loghyperparam(), c["final_hp"], atol=5e-5)
+    final = b.get_loghyperparam()
+    print("bcm16_cg_8000: end point deviates by %.2e from the reference's" % np.max(np.abs(final - np.array(c["final_hp"]))))
+    assert np.allclose(final, c["final_hp"], atol=5e-5 if moving[-1] else FLAT_HP_TOL), (final, c["final_hp"])
     ll, _, _ = b.loglik_grad()
     assert abs(ll - c["final_ll"]) <= 1e-7 * abs(c["final_ll"])
     b.close()

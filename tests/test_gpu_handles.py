@@ -89,20 +89,51 @@ def test_twelve_handles_with_whole_matrix_barrier_grids(gp_mod):
 
 
 def test_more_handles_than_the_barrier_budget_serves(gp_mod):
-    """Beyond 24 live handles on a device the block's own inverse goes launch by launch (k_trtri_diag + k_trtri_level:
-    nothing waits for anything).  Same tile code in the same order: the same bits as the one-launch form."""
+    """A handle that asks for its share of the barrier budget while more than 24 handles are alive on the device gets
+    none: its block inverses go launch by launch (k_trtri_diag + k_trtri_level: nothing waits for anything).  Same tile
+    code in the same order: the same bits as the one-launch form of a handle that holds a share."""
     g = make(gp_mod, 1500, 4, 77)
     g.set_loghyperparam(HP)
-    one_launch = g.loglik_grad()
+    one_launch = g.loglik_grad()                         # alone on the device: 64 barrier workgroups reserved
     crowd = [gp_mod.Covsum(130, 4) for _ in range(25)]   # 26 live handles now
-    g.set_loghyperparam(HP + 1.0)
-    g.loglik_grad()
-    g.set_loghyperparam(HP)
-    by_launches = g.loglik_grad()
+    late = make(gp_mod, 1500, 4, 77)                     # the same data in a handle that comes too late for a share
+    late.set_loghyperparam(HP)
+    by_launches = late.loglik_grad()
     for c in crowd:
         c.close()
     assert one_launch[0] == by_launches[0] and tuple(one_launch[1]) == tuple(by_launches[1])
     g.close()
+    late.close()
+
+
+def test_graphs_captured_before_more_handles_arrive(gp_mod):
+    """a captured graph bakes its k_trtri_block grid in.  Six overlap-off handles capture their graphs
+    with 64 barrier workgroups each (the whole pool of 384); six more handles created afterwards must not push the sum
+    over the 512 workgroup slots -- they get what is left of the pool (nothing: launch by launch), the first six keep their
+    reserved grids, and all twelve in flight together finish with the bits each gets alone."""
+    rows = [1153, 1300, 1500, 1700, 1900, 2048, 1200, 1400, 1600, 1800, 2000, 1250]      # 10..16 tiles: graph replays
+    first = [make(gp_mod, n, 4, 500 + i) for i, n in enumerate(rows[:6])]
+    for g in first:
+        g.set_overlap(False)
+        g.set_loghyperparam(HP)
+    alone = [g.loglik_grad() for g in first]             # captures each handle's graph
+    second = [make(gp_mod, n, 4, 506 + i) for i, n in enumerate(rows[6:])]
+    for g in second:
+        g.set_overlap(False)
+        g.set_loghyperparam(HP)
+    alone += [g.loglik_grad() for g in second]
+    hs = first + second
+    for r in range(3):
+        for g in hs:
+            g.set_loghyperparam(HP + (1e-3 * r if r else 0.0))
+            g.enqueue(True)
+        res = [g.fetch() for g in hs]                    # (a stage wait that ran out raises CUGP_ERR_DEVICE here)
+        assert all(np.isfinite(ll) and np.all(np.isfinite(gr)) for ll, gr in res)
+        if r == 0:
+            for a, b in zip(res, alone):
+                assert a[0] == b[0] and tuple(a[1]) == tuple(b[1])
+    for g in hs:
+        g.close()
 
 
 @pytest.mark.parametrize("n", [130, 515, 900, 1500, 2100, 2500])

@@ -238,8 +238,7 @@ def test_big_golden_4096(gp_mod, sine):
     """config 2 (sine_dataset_4096_10, log-lik matches CPU to 1e-8) -- only when the fixture exists."""
     import json, os
     p = os.path.join(os.path.dirname(__file__), "golden", "golden_big_4096.json")
-    if not os.path.exists(p):
-        pytest.skip("golden_big_4096.json not generated")
+    assert os.path.exists(p), "tests/golden/golden_big_4096.json is missing (a committed fixture: failing, not skipping)"
     c = json.load(open(p))["cases"]["sine_4096"]
     Xq, yq = sine
     X, y = np.ascontiguousarray(Xq[:4096]), np.ascontiguousarray(yq[:4096])
@@ -257,8 +256,7 @@ def test_big_golden_8192(gp_mod):
     import json, os
     g = os.path.join(os.path.dirname(__file__), "golden")
     p, d = os.path.join(g, "golden_big_8192.json"), os.path.join(g, "data_siproper_9192.npz")
-    if not (os.path.exists(p) and os.path.exists(d)):
-        pytest.skip("golden_big_8192.json not generated")
+    assert os.path.exists(p) and os.path.exists(d), "tests/golden/golden_big_8192.json / data_siproper_9192.npz missing (committed fixtures: failing, not skipping)"
     c = json.load(open(p))["cases"]["siproper_8192"]
     z = np.load(d)
     X, y = np.ascontiguousarray(z["X"][:8192]), np.ascontiguousarray(z["y"][:8192])
@@ -744,12 +742,14 @@ def test_cg_sparing_on_the_gpu(gp_mod, si128, golden_si128):
     g.close()
 
 
-def test_sharded_bcm_device_rows_with_rccl_single_rank(tmp_path):
-    """The one-process-per-GPU layout on the one GPU of this box: a 1-rank NCCL (= RCCL) process group, the
-    per-expert rows written into the device tensor by cugp_bcm_loglik_grad_rows_device and all-reduced there.
+@pytest.mark.parametrize("form", ["library", "allgather", "allreduce"])
+def test_sharded_bcm_device_rows_with_rccl_single_rank(tmp_path, form):
+    """The one-process-per-GPU layout on the one GPU of this box: a 1-rank NCCL (= RCCL) process group and every form
+    of the per-evaluation exchange -- `library` (the default under RCCL: a communicator of the library's own, the
+    all-gather on the evaluation's stream, csrc/comm.cpp), `allgather` and `allreduce` (through torch.distributed).
     (More ranks need more GPUs; the sharding / ordered sum itself is covered on 2 gloo ranks in
     tests/test_distributed_gloo.py.)  Runs in a child process: a process group is process-global state."""
-    import subprocess, sys, textwrap
+    import os, subprocess, sys, textwrap
     from conftest import ROOT
     script = tmp_path / "rank0.py"
     script.write_text(textwrap.dedent('''
@@ -765,8 +765,9 @@ def test_sharded_bcm_device_rows_with_rccl_single_rank(tmp_path):
         X, y = synth(3 * 300, 5, seed=4)
         experts = [(X[300 * k:300 * (k + 1)], y[300 * k:300 * (k + 1)]) for k in range(3)]
         b = ShardedBCM(experts, rank=0, world=1, device=0, comm_device=torch.device("cuda", 0))
-        assert b._on_device
+        assert b._on_device and b.exchange_form == %r
         b._allreduce = lambda t: (dist.all_reduce(t, op=dist.ReduceOp.SUM), t)[1]     # force the collective at 1 rank
+        b._allgather = lambda o, m: (dist.all_gather_into_tensor(o, m), o)[1]
         b.set_loghyper(HP_DENSE)
         ll, g, per = b.loglik_grad()
         ref = gp.BCM([300, 300, 300], 5, 0)
@@ -780,8 +781,12 @@ def test_sharded_bcm_device_rows_with_rccl_single_rank(tmp_path):
         b.close(); ref.close()
         dist.destroy_process_group()
         print("RCCL_SINGLE_RANK_OK")
-        ''' % (ROOT, ROOT)))
-    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300)
+        ''' % (ROOT, ROOT, form)))
+    env = dict(os.environ)
+    env.pop("CUGP_BCM_EXCHANGE", None)
+    if form != "library":
+        env["CUGP_BCM_EXCHANGE"] = form
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0 and "RCCL_SINGLE_RANK_OK" in out.stdout, (out.stdout[-2000:], out.stderr[-3000:])
 
 
@@ -924,7 +929,8 @@ def _two_rank_device_rows_worker(rank, world, port, q):
     assert b._on_device and b.mine == [k for k in range(K) if k % world == rank]
     b.set_loghyper([np.log(3.0), 0.0, np.log(0.1)])
     ll, g, per = b.loglik_grad()
-    send = b._send.cpu().numpy()
+    assert b.exchange_form == "allgather"                 # (gloo moves the device tensors; RCCL would refuse two ranks on one GPU)
+    send = b._mine_dev.cpu().numpy()                      # this rank's compact rows, as the library left them on the device
     q.put((rank, ll, g, per, send))
     dist.barrier()
     b.close()
@@ -932,9 +938,10 @@ def _two_rank_device_rows_worker(rank, world, port, q):
 
 
 def test_two_ranks_device_rows_slots_and_zeros(gp_mod):
-    """The device-resident row path of ShardedBCM (cugp_bcm_loglik_grad_rows_device -> all-reduce of the K x 4 device
-    tensor) with TWO ranks, both on GPU 0 of this box (gloo moves the device tensors): every rank's rows land in its
-    own slots, every other slot is an exact zero, and the all-reduced sums equal the single-process BCM bit for bit."""
+    """The device-resident row path of ShardedBCM (cugp_bcm_loglik_grad_rows_device -> all-gather of every rank's
+    [per, 4] device rows) with TWO ranks, both on GPU 0 of this box (gloo moves the device tensors): 5 experts, so rank 0
+    owns 3 and rank 1 owns 2 -- every rank's rows land in its own slots in local order, the slot rank 1 does not use is
+    an exact zero, and the sums over the gathered rows equal the single-process BCM bit for bit."""
     import socket
     import torch.multiprocessing as mp
     s = socket.socket()
@@ -959,8 +966,9 @@ def test_two_ranks_device_rows_slots_and_zeros(gp_mod):
     b.close()
     for rank, rll, rg, rper, send in res:
         assert rll == ll and np.array_equal(rg, g) and np.array_equal(rper, per)
-        for k in range(K):
-            if k % 2 == rank:
-                assert np.array_equal(send[k], ref_rows[k]), (rank, k)
-            else:
-                assert np.all(send[k] == 0.0), (rank, k, send[k])
+        mine = [k for k in range(K) if k % 2 == rank]
+        assert send.shape == (3, 4)                           # per = ceil(5 / 2)
+        for i, k in enumerate(mine):
+            assert np.array_equal(send[i], ref_rows[k]), (rank, k)
+        for i in range(len(mine), 3):
+            assert np.all(send[i] == 0.0), (rank, i, send[i])

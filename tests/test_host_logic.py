@@ -157,7 +157,7 @@ def test_row_partition_matches_reference(oracle, si128):
 # ---------------------------------------------------------------------------------------------
 
 
-def _replay_potrf_plan(nt, P, near):
+def _replay_potrf_plan(nt, P, near, S=1):
     """Replay the schedule on a set model.  applied[(i, j)] = k tiles subtracted from tile (i, j) so far, in
     launch order (one in-order stream).  Checks that every tile has seen exactly k = 0..j-1, ascending, when its
     column is solved / its diagonal block factored, and that the far boundary never moves backwards."""
@@ -165,9 +165,13 @@ def _replay_potrf_plan(nt, P, near):
     applied = {(i, j): [] for j in range(nt) for i in range(j, nt)}
     last_far = 0
     for kb in range(nt - 1):
-        out = (C.c_int * 5)()
-        assert lib.cugp_potrf_plan(nt, P, near, kb, out) == 0
-        k0, kw, a0, a1, wcol = list(out)
+        out = (C.c_int * 6)()
+        assert lib.cugp_potrf_plan_sub(nt, P, near, S, kb, out) == 0
+        k0, kw, a0, a1, wcol, ks = list(out)
+        if S == 1:
+            out5 = (C.c_int * 5)()
+            assert lib.cugp_potrf_plan(nt, P, near, kb, out5) == 0 and list(out5) == [k0, kw, a0, a1, wcol] and ks == kb
+        assert 0 <= ks <= kb and kb - ks < 4                         # at most SUBPANEL_MAX k tiles per pass
         # panel solve of column kb: every tile of the column is up to date
         for i in range(kb, nt):
             assert applied[(i, kb)] == list(range(kb)), (nt, P, near, kb, i, applied[(i, kb)])
@@ -177,17 +181,18 @@ def _replay_potrf_plan(nt, P, near):
         if a1 > a0:
             p = kb // P
             assert (k0, kw) == (p * P, P) and k0 + kw == kb + 1      # the panel just completed ...
-            assert (a0, a1) == (far, nt)                             # ... goes to everything beyond the window
+            assert a0 >= far and a1 == nt                            # ... goes to everything beyond the window
+            assert a0 == far or wcol == 1                            # (a left-looking sub-panel step touches one column)
             assert a0 >= last_far                                    # the far boundary never moves backwards
             last_far = a0
             for j in range(a0, a1):
                 for i in range(j, nt):
                     applied[(i, j)] += list(range(k0, k0 + kw))
         else:
-            assert far == nt or kb % P != P - 1
+            assert far == nt or kb % P != P - 1 or P == 1           # (P = 1 has no wide passes: the window is the whole trailing matrix)
         for j in range(kb + 1, far):
             for i in range(j, nt):
-                applied[(i, j)] += [kb]
+                applied[(i, j)] += list(range(ks, kb + 1))
         # the diagonal block factored inside this launch
         assert applied[(kb + 1, kb + 1)] == list(range(kb + 1)), (nt, P, near, kb, applied[(kb + 1, kb + 1)])
     for (i, j), ks in applied.items():
@@ -199,6 +204,8 @@ def test_potrf_plan_covers_every_update_exactly_once_in_order():
         for near in (1, 40, 300, 500, 700, 5000):
             for nt in list(range(2, 30)) + [40, 63, 64, 79]:
                 _replay_potrf_plan(nt, P, near)
+                for S in (2, 4):                             # sub-panelled near window (tuning key 17)
+                    _replay_potrf_plan(nt, P, near, S)
 
 
 def test_cg_sparing_takes_the_default_trajectory_with_fewer_gradients(oracle, si128):

@@ -142,8 +142,7 @@ def test_oracle_on_si24000_shards(oracle):
     log-likelihoods the reference's BCM printed (6 decimals), and the dense-hp gradient contribution stays finite.
     (The full 16-shard sum and the 6000-/8192-/10000-row cases are GPU tests: the oracle needs minutes to hours there.)"""
     p = os.path.join(GOLDEN, "golden_r2", "si24000_bcm16.json")
-    if not os.path.exists(p):
-        pytest.skip("golden_r2/si24000_bcm16.json not generated")
+    assert os.path.exists(p), "golden_r2/si24000_bcm16.json is missing (a committed fixture)"
     c = json.load(open(p))["cases"][0]
     d = np.load(os.path.join(GOLDEN, "data_si24000.npz"))
     for k in (0, 15):
@@ -151,3 +150,20 @@ def test_oracle_on_si24000_shards(oracle):
         y = np.ascontiguousarray(d["y"][1500 * k:1500 * (k + 1)])
         ll = oracle.loglik(X, y, c["hp"])
         assert abs(ll - c["ll_per_expert_6dp"][k]) <= 6e-7, (k, ll, c["ll_per_expert_6dp"][k])
+
+
+def test_every_listed_golden_job_is_committed():
+    """Every reference job tests/golden/run_jobs.sh runs (make_golden.py JOBS / JOBS_R3 / JOBS_R4) has its fixture in the
+    tree, and so have the big single-matrix cases: the GPU tests that read them FAIL on a missing file, and this test says
+    so on the CPU already (a deleted golden must not read as green)."""
+    import ast
+    src = open(os.path.join(GOLDEN, "make_golden.py")).read()
+    names = []
+    for node in ast.walk(ast.parse(src)):
+        if isinstance(node, ast.Assign) and any(getattr(t, "id", "") in ("JOBS", "JOBS_R3", "JOBS_R4") for t in node.targets):
+            names += list(eval(compile(ast.Expression(node.value), "make_golden.py", "eval"), {"range": range}))   # (plain list arithmetic)
+    assert len(names) >= 30
+    missing = [n for n in names if not os.path.exists(os.path.join(GOLDEN, "golden_r2", n + ".json"))]
+    assert not missing, missing
+    for f in ("golden_big_4096.json", "golden_big_8192.json", "data_siproper_9192.npz", "data_si24000.npz"):
+        assert os.path.exists(os.path.join(GOLDEN, f)), f

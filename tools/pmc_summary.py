@@ -14,7 +14,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out")
-tag = sys.argv[2] if len(sys.argv) > 2 else "r05"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r06"
+sys.path.insert(0, ROOT)
+from cugp_amd import build as _build    # noqa: E402   (source_hash: the id compiled into the library that was profiled)
 CLOCK_HZ, SIMDS = 2.4e9, 256 * 4
 KERNELS = ("k_syrk_step", "k_syrk_wide", "k_lauum<4>", "k_lauum<2>", "k_trtri_level<4>", "k_trtri_level<2>",
            "k_trtri_border<4>", "k_trtri_border<2>", "k_trtri_diag", "k_trtri_block", "k_build", "k_trace", "k_potf2",
@@ -34,7 +36,23 @@ def short(name):
     return None
 
 
-out = {"note": __doc__.strip(), "kernels": {}}
+def git_head():
+    try:
+        import subprocess
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        return os.environ.get("CUGP_GIT_HEAD")          # (the GPU box has no .git: tools/make_profiles.sh may pass it)
+
+
+# build_id: hash of the library's sources as they are in THIS tree (the library in the tree was built from them:
+# cugp_amd/build.py rebuilds when its recorded id differs); bench.py reports roofline.traffic from this file only
+# when the library it has loaded carries the same id
+idfile = os.path.join(ROOT, "cugp_amd", "lib", "libcugp.id")
+built = open(idfile).read().strip() if os.path.exists(idfile) else None
+out = {"note": __doc__.strip(), "build_id": _build.source_hash(), "library_id_file": built, "git_head": git_head(),
+       "kernels": {}}
+if built and built != out["build_id"]:
+    raise SystemExit("the library in the tree (%s) was not built from the sources in the tree (%s): rebuild, re-profile" % (built, out["build_id"]))
 for t, key in (("FETCH_SIZE", "fetch_kib_raw"), ("WRITE_SIZE", "write_kib")):
     agg, n = collections.defaultdict(float), collections.Counter()
     for r in load(t):
