@@ -689,8 +689,8 @@ int enqueue_potrf(cugp_gp* g, bool with_inverse, bool mark = false, const unsign
     g->eval_seq++;
     const unsigned* my_tickets = g->grp ? g->grp->tickets : g->dtickets;
     if (zeroed_tickets && zeroed_tickets == my_tickets) {}   // (the covariance build in front of it did that)
-    else if (g->grp) HIPCHK(hipMemsetAsync(g->grp->tickets, 0, (size_t)g->grp->bt.count * 2 * nt * sizeof(unsigned), m));
-    else HIPCHK(hipMemsetAsync(g->dtickets, 0, (size_t)2 * nt * sizeof(unsigned), m));
+    else if (g->grp) HIPCHK(hipMemsetAsync(g->grp->tickets, 0, (size_t)g->grp->bt.count * ticket_count(nt) * sizeof(unsigned), m));
+    else HIPCHK(hipMemsetAsync(g->dtickets, 0, (size_t)ticket_count(nt) * sizeof(unsigned), m));
     launch_potf2(g->dA, ld, 0, g->d16, g->d64, g->dlogdet, m, B(g));
     const bool zf = g->zfuse && !with_inverse;              // (LL-only: z = L^-1 y inside the panel-solve and step launches)
     g->last_main = -1;
@@ -806,8 +806,9 @@ int record_eval(cugp_gp* g, bool want_grad, const HyperScalars* hd)
             launch_trmv_lower(g->dT, g->npad, g->npad, g->dy, g->dz, s, B(g));        // z = L^-1 y
             launch_trmv_upper(g->dU, g->npad, g->npad, g->dz, g->dalpha, s, B(g));    // alpha = L^-T z
         }
-        launch_trace(g->dX, g->n, g->d, g->npad, h, g->dKinv, g->dalpha, g->dpart, s, hd, B(g));
-        launch_finalize(g->dz, g->npad, g->n, g->dlogdet, g->nt, g->dpart, g->nblocks_trace, h, g->dout, host_out(g), s, hd, B(g));
+        // traces and the final sums in ONE launch: the last block of k_trace finishes the evaluation (kernels.hip)
+        launch_trace(g->dX, g->n, g->d, g->npad, h, g->dKinv, g->dalpha, g->dpart, s, hd, B(g), g->dz, g->dlogdet, g->dout,
+                     host_out(g), tickets + 2 * g->nt);
     } else {
         if ((rc = phase_mark(g, 3))) return rc;
         if ((rc = phase_mark(g, 4))) return rc;
@@ -889,13 +890,13 @@ int enqueue_continue(cugp_gp* g)
     const HyperScalars h = scalars(g);
     hipStream_t s = g->stream;
     g->inverse_valid = false;
-    HIPCHK(hipMemsetAsync(g->dtickets + g->nt, 0, (size_t)g->nt * sizeof(unsigned), s));     // k_trtri_block's stage counters
+    HIPCHK(hipMemsetAsync(g->dtickets + g->nt, 0, (size_t)(g->nt + 1) * sizeof(unsigned), s));     // k_trtri_block's stage counters, k_trace's arrival counter
     if ((rc = reset_stamps(g))) return rc;
     if ((rc = enqueue_inverse_block(g, 0, g->nt, true, s, nullptr, nullptr))) return rc;
     launch_trmv_lower(g->dT, g->npad, g->npad, g->dy, g->dz, s);
     launch_trmv_upper(g->dU, g->npad, g->npad, g->dz, g->dalpha, s);
-    launch_trace(g->dX, g->n, g->d, g->npad, h, g->dKinv, g->dalpha, g->dpart, s);
-    launch_finalize(g->dz, g->npad, g->n, g->dlogdet, g->nt, g->dpart, g->nblocks_trace, h, g->dout, g->hout, s);
+    launch_trace(g->dX, g->n, g->d, g->npad, h, g->dKinv, g->dalpha, g->dpart, s, nullptr, {}, g->dz, g->dlogdet, g->dout, g->hout,
+                 g->dtickets + 2 * g->nt);
     HIPCHK(hipGetLastError());
     g->pending = true;
     g->pending_grad = true;
@@ -1016,7 +1017,7 @@ int cugp_create_padded(int n, int d, int device, int npad_min, cugp_gp** out)
     if (e == hipSuccess) e = hipMalloc((void**)&g->dlogdet, (size_t)g->nt * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&g->dpart, (size_t)g->nblocks_trace * 3 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc((void**)&g->dout, 8 * sizeof(double));
-    if (e == hipSuccess) e = hipMalloc((void**)&g->dtickets, (size_t)2 * g->nt * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc((void**)&g->dtickets, (size_t)ticket_count(g->nt) * sizeof(unsigned));
     if (e == hipSuccess) e = hipHostMalloc((void**)&g->hout, 8 * sizeof(double), hipHostMallocDefault);
     if (e == hipSuccess) memset(g->hout, 0, 8 * sizeof(double));   // (entry 6 is the status word fetch_eval reads)
     if (e == hipSuccess) e = hipHostMalloc((void**)&g->hhs, sizeof(HyperScalars), hipHostMallocDefault);
@@ -1198,6 +1199,7 @@ static int predict_device(cugp_gp* g, const double* Xt, int nt, double** dmean_o
     int rc;
     if ((rc = cugp_loglik_grad(g, nullptr, nullptr))) return rc;     // factor, T, alpha for the current hp
     if ((rc = use_device(g))) return rc;                             // (a BCM over several devices predicts expert by expert)
+    TuneScope ts(g);
     const int ntpad = ((nt + TILE - 1) / TILE) * TILE;
     const HyperScalars h = scalars(g);
     // prediction scratch lives with the handle and only grows (the allocations cost more than the kernels
@@ -1288,6 +1290,7 @@ int cugp_compute_K_train(cugp_gp* g, double* K)
     if ((rc = fetch_eval(g))) return rc;
     if ((rc = ensure(&g->dA, (size_t)g->npad * g->npad))) return rc;
     g->factor_valid = g->inverse_valid = false;
+    TuneScope ts(g);
     launch_kbuild(g->dX, g->n, g->d, g->npad, scalars(g), g->dA, true, g->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpy2DAsync(K, (size_t)g->n * sizeof(double), g->dA, (size_t)g->npad * sizeof(double),
@@ -1325,6 +1328,7 @@ int cugp_compute_k_test(cugp_gp* g, const double* Xt, int nt, double* Ks)
     hipError_t e = hipMalloc((void**)&dKs, (size_t)ntpad * g->npad * sizeof(double));
     if (e == hipSuccess) e = hipMemcpyAsync(dXt, Xt, (size_t)nt * g->d * sizeof(double), hipMemcpyHostToDevice, g->stream);
     if (e == hipSuccess) {
+        TuneScope ts(g);
         launch_kcross(g->dX, g->n, g->d, g->npad, dXt, nt, ntpad, scalars(g), dKs, g->stream);
         e = hipMemcpy2DAsync(Ks, (size_t)g->n * sizeof(double), dKs, (size_t)g->npad * sizeof(double),
                              (size_t)g->n * sizeof(double), nt, hipMemcpyDeviceToHost, g->stream);
@@ -1794,7 +1798,7 @@ int cugp_group_create(cugp_gp* const* experts, int k, cugp_group** out)
     const int nt = experts[0]->nt;
     hipError_t e = hipSetDevice(experts[0]->device);
     if (e == hipSuccess) e = hipMalloc((void**)&gr->dtab, (size_t)k * sizeof(ExpertPtrs));
-    if (e == hipSuccess) e = hipMalloc((void**)&gr->ctx.tickets, (size_t)k * 2 * nt * sizeof(unsigned));
+    if (e == hipSuccess) e = hipMalloc((void**)&gr->ctx.tickets, (size_t)k * ticket_count(nt) * sizeof(unsigned));
     if (e == hipSuccess) e = hipMalloc((void**)&gr->ctx.dout, (size_t)k * 8 * sizeof(double));
     if (e == hipSuccess) e = hipHostMalloc((void**)&gr->ctx.hout, (size_t)k * 8 * sizeof(double), hipHostMallocDefault);
     if (e == hipSuccess) memset(gr->ctx.hout, 0, (size_t)k * 8 * sizeof(double));   // (entry 6 of a row: status word)
@@ -1857,7 +1861,7 @@ int cugp_group_enqueue(cugp_group* gr, int want_grad)
             cugp_gp* e = gr->experts[i];
             tab[i] = ExpertPtrs{e->dA, e->dT, e->dU, e->dKinv, e->d16, e->d64, e->dlogdet, e->dy, e->dz, e->dalpha,
                                 e->dw, e->dpart, gr->ctx.dout + (size_t)i * 8, e->dX,
-                                gr->ctx.tickets + (size_t)i * 2 * nt, e->n};
+                                gr->ctx.tickets + (size_t)i * ticket_count(nt), e->n};
         }
         HIPCHK(hipStreamSynchronize(lead->stream));           // a captured graph may still be reading the old table
         HIPCHK(hipMemcpy(gr->dtab, tab.data(), tab.size() * sizeof(ExpertPtrs), hipMemcpyHostToDevice));

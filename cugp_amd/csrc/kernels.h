@@ -23,7 +23,7 @@ enum { TUNE_LAUUM_WM2_MAX = 0,   // K^-1 product: use 64x64 tiles when there are
        TUNE_NEAR_TILES = 9,      // ... tiles in the near window (updated every step, K = 128) at a panel's first step
        TUNE_PANEL_MIN_NT = 10,   // ... only from this many tiles on (small matrices are bound by the chain alone)
        TUNE_LAUUM_STREAM = 11,   // the K^-1 share of an inverse block on its own stream beside the next block's bordering: 0 never, 1 expert groups only, 2 always
-       TUNE_STEP_STREAM = 12,    // (no effect since round 5: the C tile of every accumulate-form product is read and written in the epilogue with plain accesses -- non-temporal ones lost 1-3 TF/s there; rounds 2-4: non-temporal accesses to the step kernel's C tiles)
+       TUNE_FINALIZE_FUSE_MAX = 12, // gradient evaluations: the last block of k_trace takes the final sums (no k_finalize launch) when the trace launch has at most this many blocks; 0 = always the separate launch
        TUNE_SPLIT_REM_MAX = 13,  // uniform-K launches (block-wise K^-1 share, bordering, wide update): a last round of at most this many tiles runs as 64x64 quarters
        TUNE_STEP_QUARTER_MAX = 14, // step kernel: launches of at most this many 64x64 workgroups run ALL their tiles as quarters (chain-bound tail)
        TUNE_STREAM_PRIO = 15,    // read when a handle is created: bit 0 = the factorisation's stream at the highest priority, bit 1 = the inverse streams at the lowest (default 0: prioritised streams serialised grouped experts in round 3)
@@ -132,9 +132,15 @@ void launch_trsv_lower(const double* A, const double* T, int ld, int nt, const d
 void launch_copy_y_to_w(int npad, hipStream_t s, Batch bt);                                            // batched only
 // gradient traces (N10+N11 fused): partial sums per block into part[3*nblocks]
 int trace_num_blocks(int npad);
+// out (when given): the launch also FINISHES the evaluation -- its last block (an arrival ticket, zero before the launch)
+// takes the final sums and writes out[0..5] (and hout) as launch_finalize would: z, logdet_part as there; batched:
+// taken from the experts' table, ticket = tickets[2 nt] of every expert
 void launch_trace(const double* X, int n, int d, int npad, HyperScalars h, const double* Kinv,
                   const double* alpha, double* part, hipStream_t s, const HyperScalars* hd = nullptr,
-                  Batch bt = {});
+                  Batch bt = {}, const double* z = nullptr, const double* logdet_part = nullptr, double* out = nullptr,
+                  double* hout = nullptr, unsigned* ticket = nullptr);
+// arrival counters per expert: [0, nt) step tickets, [nt, 2 nt) stage counters of k_trtri_block, [2 nt] k_trace's fused finalize
+constexpr int ticket_count(int nt) { return 2 * nt + 1; }
 // out[0..3] = LL, g0, g1, g2  (LL only when part == nullptr)
 void launch_finalize(const double* z, int npad, int n, const double* logdet_part, int nt, const double* part,
                      int nblocks, HyperScalars h, double* out, double* hout, hipStream_t s,

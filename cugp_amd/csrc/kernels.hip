@@ -953,9 +953,10 @@ __global__ __launch_bounds__(256) void k_build(const double* __restrict__ X, int
     }
     // tickets (when given): the factorisation's per-step arrival counters, zeroed here instead of by a memset node in
     // front of the factorisation (one launch boundary less on a chain that small matrices are bound by)
-    // (2 per tile row: [0, nt) the step tickets of k_syrk_step, [nt, 2 nt) the stage counters of k_trtri_block)
+    // (2 per tile row: [0, nt) the step tickets of k_syrk_step, [nt, 2 nt) the stage counters of k_trtri_block; [2 nt]: the
+    //  arrival counter of k_trace's fused finalize)
     if (tickets && blockIdx.x == 0)
-        for (int i = threadIdx.x; i < 2 * (npad / TILE); i += 256) tickets[i] = 0u;
+        for (int i = threadIdx.x; i < ticket_count(npad / TILE); i += 256) tickets[i] = 0u;
     const HyperScalars h = hd ? *hd : h_arg;
     __shared__ double xs[KT][DC + 1], ys[KT][DC + 1];
     int ti, tj;
@@ -2128,19 +2129,106 @@ __global__ __launch_bounds__(256) void k_trsv_update(const double* __restrict__ 
     if (lane == 0) w[row] -= s;
 }
 
+// Final sums of an evaluation by ONE workgroup of NTHR threads, in the order 1024 threads would take them whatever NTHR
+// is (so the stand-alone k_finalize, 1024 threads, and the last block of k_trace, 256 threads, give the same bits):
+// virtual thread v = 0..1023 sums the entries i = v, v + 1024, ... ascending, then the halving tree red[v] += red[v + w],
+// w = 512 .. 1.  A real thread takes the virtual threads t, t + NTHR, ... and the tree levels above NTHR in registers.
+// HANDED: the trace partials were written by other workgroups of this launch -- agent-scope loads.
+// red: 5 * NTHR / ... doubles of LDS: [5][NTHR].
+constexpr int FIN_THREADS = 1024;     // one workgroup; at N = 8192 it sums 3 x 8256 trace partials and 8192 squares (23 us with 256 threads)
+template <int NTHR, bool HANDED>
+__device__ __forceinline__ void finalize_sums(const double* __restrict__ z, int npad, int n,
+                                              const double* __restrict__ logdet_part, int nt,
+                                              const double* __restrict__ part, int nblocks, HyperScalars h,
+                                              double* __restrict__ out, double* __restrict__ hout, double* red)
+{
+    constexpr int V = FIN_THREADS / NTHR;              // virtual threads per real thread
+    const int t = threadIdx.x;
+    double acc[5][V];
+#pragma unroll
+    for (int j = 0; j < V; j++) {
+        const int v = t + j * NTHR;
+        double q = 0.0, ld = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
+        for (int i = v; i < npad; i += FIN_THREADS) q += z[i] * z[i];
+        for (int i = v; i < nt; i += FIN_THREADS) ld += logdet_part[i];
+        if (part)
+            for (int i0 = v; i0 < nblocks; i0 += 4 * FIN_THREADS) {
+                // four entries' loads in flight before the first is added (agent-scope loads one by one cost a memory
+                // latency each: 40 us for the 8256 partials of an 8192-row matrix); the sums are taken in order
+                double p[4][3];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i = i0 + u * FIN_THREADS;
+                    const double* pp = part + (size_t)(i < nblocks ? i : v) * 3;
+#pragma unroll
+                    for (int c = 0; c < 3; c++)
+                        p[u][c] = HANDED ? __hip_atomic_load(pp + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : pp[c];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (i0 + u * FIN_THREADS < nblocks) { s0 += p[u][0]; s1 += p[u][1]; s2 += p[u][2]; }
+            }
+        acc[0][j] = q; acc[1][j] = ld; acc[2][j] = s0; acc[3][j] = s1; acc[4][j] = s2;
+    }
+    // tree levels w >= NTHR: red[v] += red[v + w] pairs virtual threads of the SAME real thread (v and v + w differ by a multiple of NTHR)
+#pragma unroll
+    for (int w = V / 2; w > 0; w >>= 1)
+#pragma unroll
+        for (int c = 0; c < 5; c++)
+#pragma unroll
+            for (int j = 0; j < w; j++) acc[c][j] += acc[c][j + w];
+    __syncthreads();                                   // (red may alias LDS the caller used before)
+#pragma unroll
+    for (int c = 0; c < 5; c++) red[c * NTHR + t] = acc[c][0];
+    __syncthreads();
+    for (int w = NTHR / 2; w > 0; w >>= 1) {
+        if (t < w)
+            for (int c = 0; c < 5; c++) red[c * NTHR + t] += red[c * NTHR + t + w];
+        __syncthreads();
+    }
+    if (t == 0) {
+        const double quad = red[0], logdet = 2 * red[NTHR];
+        out[0] = -0.5 * (quad + logdet + n * 1.83787);
+        if (part) {
+            const double s1 = red[2 * NTHR], s2 = red[3 * NTHR], s3 = red[4 * NTHR];
+            out[1] = s1 / 2.0;
+            out[2] = (2.0 * s2 - 2.0 * h.noise_var * s3) / 2.0;
+            out[3] = (2.0 * h.noise_var * s3) / 2.0;
+        }
+        out[4] = quad;
+        out[5] = logdet;
+        if (hout)
+            for (int i = 0; i < 6; i++) hout[i] = out[i];
+    }
+}
+
+// what the last block of k_trace needs to finish the evaluation (out == nullptr: no fused finalize)
+struct FinalizeArgs {
+    const double* z; const double* logdet_part; int nt; double* out; double* hout; unsigned* ticket;
+};
+
 // gradient traces, fused: for every lower 64x64 tile recompute k(xi,xj) and |xi-xj|^2/l^2, read K^-1 once,
 // W = K^-1 - alpha alpha^T, accumulate  s1 = sum W*K*S, s2 = sum W*K, s3 = sum_i W_ii  (off-diagonal tiles x2)
 __global__ __launch_bounds__(256) void k_trace(const double* __restrict__ X, int n, int d, int npad,
                                                HyperScalars h_arg, const HyperScalars* __restrict__ hd,
                                                const double* __restrict__ Kinv, const double* __restrict__ alpha,
-                                               double* __restrict__ part, const ExpertPtrs* __restrict__ bt)
+                                               double* __restrict__ part, const ExpertPtrs* __restrict__ bt,
+                                               FinalizeArgs fin)
 {
     if (bt) {
         const ExpertPtrs& e = bt[blockIdx.y];
         X = GP(e.X); n = e.n; Kinv = GP(e.Kinv); alpha = GP(e.alpha); part = GP(e.part);
+        if (fin.out) {
+            fin.z = GP(e.z); fin.logdet_part = GP(e.logdet); fin.out = GP(e.out); fin.ticket = GP(e.tickets) + 2 * fin.nt;
+            if (fin.hout) fin.hout += (size_t)blockIdx.y * 8;
+        }
     }
     const HyperScalars h = hd ? *hd : h_arg;
-    __shared__ double xs[KT][DC + 1], ys[KT][DC + 1];
+    // (one buffer: the two X tiles of the squared distances, later the [5][256] sums of the fused finalize)
+    __shared__ double lds[2 * KT * (DC + 1)];
+    static_assert(2 * KT * (DC + 1) >= 5 * 256, "the fused finalize reduces in the X tiles' LDS");
+    double (&xs)[KT][DC + 1] = *reinterpret_cast<double (*)[KT][DC + 1]>(lds);
+    double (&ys)[KT][DC + 1] = *reinterpret_cast<double (*)[KT][DC + 1]>(lds + KT * (DC + 1));
     __shared__ double red[3][4];
     int ti, tj;
     tri_index(blockIdx.x, ti, tj);
@@ -2182,13 +2270,31 @@ __global__ __launch_bounds__(256) void k_trace(const double* __restrict__ X, int
     s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
     if ((t & 63) == 0) { red[0][t >> 6] = s1; red[1][t >> 6] = s2; red[2][t >> 6] = s3; }
     __syncthreads();
-    if (t < 3) part[(size_t)blockIdx.x * 3 + t] = (red[t][0] + red[t][1]) + (red[t][2] + red[t][3]);
+    if (!fin.out) {
+        if (t < 3) part[(size_t)blockIdx.x * 3 + t] = (red[t][0] + red[t][1]) + (red[t][2] + red[t][3]);
+        return;
+    }
+    // Fused finalize (round 6): the partial sums leave write-through, the block draws a ticket, and the LAST block of the
+    // launch (of this expert) goes on to the final sums and the scalar formulas -- what k_finalize did as one more launch
+    // behind this one (a kernel boundary and a 1-workgroup launch on the serial tail of every evaluation: ~9 us of a
+    // 590-us evaluation at 1500 rows).  The hand-off is the step kernel's (k_syrk_step): write-through (agent-scope)
+    // stores by lanes of wave 0, that wave's vmcnt(0), one relaxed agent-scope ticket; the last arriver reads every
+    // partial with agent-scope loads.  Same sums in the same order as k_finalize: identical bits.
+    __shared__ unsigned s_ticket;
+    if (t < 3) __hip_atomic_store(part + (size_t)blockIdx.x * 3 + t, (red[t][0] + red[t][1]) + (red[t][2] + red[t][3]),
+                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (t == 0) s_ticket = __hip_atomic_fetch_add(fin.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_ticket != gridDim.x - 1) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (t == 0) *fin.ticket = 0u;                          // (ready for the next evaluation; nobody else touches it any more)
+    finalize_sums<256, true>(fin.z, npad, n, fin.logdet_part, fin.nt, part, (int)gridDim.x, h, fin.out, fin.hout, lds);
 }
 
 // single workgroup: deterministic final sums and the scalar formulas
 //   LL = -0.5 (z'z + 2 sum log L_ii + n * 1.83787)                     covkernel.cpp:127
 //   g0 = s1/2, g1 = (2 s2 - 2 sn2 s3)/2, g2 = (2 sn2 s3)/2              covkernel.cpp:244-261
-constexpr int FIN_THREADS = 1024;     // one workgroup; at N = 8192 it sums 3 x 8256 trace partials and 8192 squares (23 us with 256 threads)
 __global__ __launch_bounds__(FIN_THREADS) void k_finalize(const double* __restrict__ z, int npad, int n,
                                                   const double* __restrict__ logdet_part, int nt,
                                                   const double* __restrict__ part, int nblocks,
@@ -2205,36 +2311,8 @@ __global__ __launch_bounds__(FIN_THREADS) void k_finalize(const double* __restri
         if (hout) hout += (size_t)blockIdx.y * 8;
     }
     const HyperScalars h = hd ? *hd : h_arg;
-    __shared__ double red[5][FIN_THREADS];
-    const int t = threadIdx.x;
-    double q = 0.0, ld = 0.0, s[3] = {0.0, 0.0, 0.0};
-    for (int i = t; i < npad; i += FIN_THREADS) q += z[i] * z[i];
-    for (int i = t; i < nt; i += FIN_THREADS) ld += logdet_part[i];
-    if (part)
-        for (int i = t; i < nblocks; i += FIN_THREADS) {
-            s[0] += part[(size_t)i * 3]; s[1] += part[(size_t)i * 3 + 1]; s[2] += part[(size_t)i * 3 + 2];
-        }
-    red[0][t] = q; red[1][t] = ld; red[2][t] = s[0]; red[3][t] = s[1]; red[4][t] = s[2];
-    __syncthreads();
-    for (int w = FIN_THREADS / 2; w > 0; w >>= 1) {
-        if (t < w)
-            for (int c = 0; c < 5; c++) red[c][t] += red[c][t + w];
-        __syncthreads();
-    }
-    if (t == 0) {
-        const double quad = red[0][0], logdet = 2 * red[1][0];
-        out[0] = -0.5 * (quad + logdet + n * 1.83787);
-        if (part) {
-            const double s1 = red[2][0], s2 = red[3][0], s3 = red[4][0];
-            out[1] = s1 / 2.0;
-            out[2] = (2.0 * s2 - 2.0 * h.noise_var * s3) / 2.0;
-            out[3] = (2.0 * h.noise_var * s3) / 2.0;
-        }
-        out[4] = quad;
-        out[5] = logdet;
-        if (hout)
-            for (int i = 0; i < 6; i++) hout[i] = out[i];
-    }
+    __shared__ double red[5 * FIN_THREADS];
+    finalize_sums<FIN_THREADS, false>(z, npad, n, logdet_part, nt, part, nblocks, h, out, hout, red);
 }
 
 // mean[t] = Ks[t] . alpha ; var[t] = sf2 + sn2 - |W[t]|^2        covkernel.cpp:314-319
@@ -2282,7 +2360,7 @@ static inline unsigned long long* take_stamp() { unsigned long long* p = t_stamp
         }                                                                                           \
     } while (0)
 
-const int g_tune_init[TUNE_COUNT] = {768, 1200, 384, -1, 511, 1, 1, 1 << 20, 16, 500, 32, 1, 1, 256, 1536, 0, 1 << 21, 1, 1};   // defaults chosen by interleaved A/B runs (tools/ab.py)
+const int g_tune_init[TUNE_COUNT] = {768, 1200, 384, -1, 511, 1, 1, 1 << 20, 16, 500, 32, 1, 2100, 256, 1536, 0, 1 << 21, 1, 1};   // defaults chosen by interleaved A/B runs (tools/ab.py)
 thread_local const int* t_tune = g_tune_init;
 
 static inline int tri_count(int n) { return n * (n + 1) / 2; }
@@ -2553,10 +2631,18 @@ void launch_trsv_lower(const double* A, const double* T, int ld, int nt, const d
 int trace_num_blocks(int npad) { return tri_count(npad / KT); }
 
 void launch_trace(const double* X, int n, int d, int npad, HyperScalars h, const double* Kinv, const double* alpha,
-                  double* part, hipStream_t s, const HyperScalars* hd, Batch bt)
+                  double* part, hipStream_t s, const HyperScalars* hd, Batch bt, const double* z, const double* logdet_part,
+                  double* out, double* hout, unsigned* ticket)
 {
-    hipLaunchKernelGGL(k_trace, dim3(tri_count(npad / KT), bt.count), dim3(256), 0, s, X, n, d, npad, h, hd, Kinv,
-                       alpha, part, bt.tab);
+    // the last block takes the final sums where the launch is small (its 256 threads against k_finalize's 1024: at 8192
+    // rows -- 8256 blocks -- the separate launch is as fast and keeps the blocks' stores plain); TUNE_FINALIZE_FUSE_MAX
+    const int nblocks = tri_count(npad / KT);
+    const bool fuse = out != nullptr && nblocks <= tune(TUNE_FINALIZE_FUSE_MAX);
+    const FinalizeArgs fin{z, logdet_part, npad / TILE, fuse ? out : nullptr, hout, ticket};
+    hipLaunchKernelGGL(k_trace, dim3(nblocks, bt.count), dim3(256), 0, s, X, n, d, npad, h, hd, Kinv,
+                       alpha, part, bt.tab, fin);
+    if (out != nullptr && !fuse)
+        launch_finalize(z, npad, n, logdet_part, npad / TILE, part, nblocks, h, out, hout, s, hd, bt);
 }
 
 void launch_finalize(const double* z, int npad, int n, const double* logdet_part, int nt, const double* part,

@@ -17,7 +17,7 @@ import cugp_amd.gp as gp                                  # noqa: E402
 from cugp_amd import capi                                 # noqa: E402
 from conftest import synth                                # noqa: E402
 
-DEFAULT = {0: 768, 1: 1200, 2: 384, 3: -1, 4: 511, 5: 1, 6: 1, 7: 1 << 20, 8: 16, 9: 500, 10: 32, 11: 1, 12: 1, 13: 256, 14: 1536, 15: 0, 16: 1 << 21, 17: 1, 18: 1}
+DEFAULT = {0: 768, 1: 1200, 2: 384, 3: -1, 4: 511, 5: 1, 6: 1, 7: 1 << 20, 8: 16, 9: 500, 10: 32, 11: 1, 12: 2100, 13: 256, 14: 1536, 15: 0, 16: 1 << 21, 17: 1, 18: 1}
 n = int(sys.argv[1])
 names = sys.argv[2:] or ["base"]
 variants = [{} if a == "base" else dict((int(k), int(v)) for k, v in (kv.split("=") for kv in a.split(","))) for a in names]
