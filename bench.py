@@ -192,6 +192,13 @@ def main():
                     "all-reduced there (cugp_bcm_loglik_grad_rows_device)")
     args = ap.parse_args()
 
+    # stdout carries ONE line, the JSON record.  Whatever the libraries underneath print while they initialise (RCCL
+    # writes a version banner to stdout when its first communicator is created) goes to stderr: file descriptor 1 points
+    # at stderr until the record is printed.
+    sys.stdout.flush()
+    fd_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
 
@@ -533,7 +540,10 @@ def main():
                                               "the exponential): rocprofv3 --pmc SQ_INSTS_VALU ... SQ_VMEM_WR_TA_DATA_FIFO_FULL"}
         if world == 1 and args.cpu_sample > 0:
             out["cpu_baseline"] = cpu_baseline(min(args.cpu_sample, args.n), args.n, args.d)
+        sys.stdout.flush()
+        os.dup2(fd_stdout, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
 
     if collective:
         dist.barrier()

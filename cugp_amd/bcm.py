@@ -130,7 +130,27 @@ class ShardedBCM:
                 uid = bytes(idt.cpu().numpy().tobytes())
             else:
                 uid = None
-            self._comm = _gp.Comm(uid, rank, world, device)
+            try:
+                self._comm = _gp.Comm(uid, rank, world, device)
+            except Exception as exc:                      # (librccl not loadable, communicator refused, ...)
+                self._comm, self._comm_error = None, exc
+            if world > 1:
+                # every rank takes the same form: if the library's communicator failed anywhere, all ranks fall back
+                # to the all-gather through torch.distributed (the same RCCL, driven from Python) and say so
+                ok = torch.tensor([1 if self._comm is not None else 0], dtype=torch.int32,
+                                  device=comm_device if backend == "nccl" else "cpu")
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+                if int(ok.item()) == 0:
+                    if self._comm is not None:
+                        self._comm.close()
+                        self._comm = None
+                    form = self.exchange_form = "allgather"
+                    if rank == 0:
+                        print("cugp_amd.bcm: the library's RCCL communicator could not be created on every rank (%s); "
+                              "using the all-gather through torch.distributed" % getattr(self, "_comm_error", "another rank"),
+                              flush=True)
+            elif self._comm is None:
+                raise self._comm_error
         self._lean = form == "allgather"
         if self._lean:
             self._mine_dev = torch.zeros((self._per, 4), dtype=torch.float64, device=comm_device)

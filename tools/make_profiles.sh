@@ -1,7 +1,7 @@
 #!/bin/bash
 # Regenerate everything under profiles/ for one round on the GPU box:  tools/make_profiles.sh r04
 # Outputs land in gpurun_out/profiles_<tag>/ (copy the ones to keep into profiles/).
-tag=${1:-r05}
+tag=${1:-r06}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/profiles_$tag
 mkdir -p $O
@@ -24,7 +24,15 @@ cp $(find /tmp/prof_n10000 -name '*kernel_stats.csv' | head -1) $O/${tag}_bench_
 python3 $R/bench.py --rows 1500 --experts-total 16 --cpu-sample 0 > $O/${tag}_bench_bcm16_line.json 2>> $O/bench.err
 python3 $R/bench.py --rows 6000 --experts-total 4 --cpu-sample 0 --steps 10 > $O/${tag}_bench_bcm4_line.json 2>> $O/bench.err
 python3 $R/bench.py --experts-per-gpu 2 --cpu-sample 0 --steps 10 > $O/${tag}_bench_2x8192_line.json 2>> $O/bench.err
+# one rank of the 8-GPU BCM runs behind a real (one-rank) RCCL communicator: the library's exchange against the two
+# torch.distributed forms (device_ms / collective_ms / host time between evaluations, bench.py `exchange`)
+for form in library allgather allreduce; do
+  CUGP_BCM_EXCHANGE=$form python3 $R/bench.py --rehearse-rccl --experts-total 2 --rows 1500 --cpu-sample 0 --passes timed --steps 300 --warmup 30 2>> $O/bench.err | tail -1 > $O/${tag}_rehearse_2x1500_$form.json
+  CUGP_BCM_EXCHANGE=$form python3 $R/bench.py --rehearse-rccl --experts-total 1 --rows 6000 --cpu-sample 0 --passes timed --steps 40 --warmup 5 2>> $O/bench.err | tail -1 > $O/${tag}_rehearse_1x6000_$form.json
+  CUGP_BCM_EXCHANGE=$form python3 $R/bench.py --rehearse-rccl --cpu-sample 0 --passes timed --sub-steps 0 2>> $O/bench.err | tail -1 > $O/${tag}_rehearse_1x8192_$form.json
+done
 python3 $R/tools/la_bench.py > $O/${tag}_la_bench.txt 2>> $O/bench.err
+python3 $R/tools/ll_only_probe.py > $O/${tag}_ll_only.txt 2>> $O/bench.err
 python3 $R/tools/bcm_ab.py > $O/${tag}_bcm_one_gpu.txt 2>> $O/bench.err
 for mode in overlap serial; do
   rm -rf /tmp/tl_$mode
