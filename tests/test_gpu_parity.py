@@ -701,6 +701,39 @@ def test_bcm_rows_on_device(gp_mod, K):
     b.close()
 
 
+@pytest.mark.parametrize("K", [1, 3])
+def test_library_exchange_without_a_communicator(gp_mod, K):
+    """cugp_comm_* / cugp_bcm_loglik_grad_allgather (csrc/comm.cpp) in a world of one WITHOUT an id: no RCCL is opened,
+    the call evaluates the experts and returns their rows packed in local order -- the bits of cugp_bcm_loglik_grad_rows --
+    with exact zeros in the slots beyond the experts; argument errors are CUGP_ERR_INVALID, not faults."""
+    import ctypes as C
+    from cugp_amd import capi
+    X, y = synth(K * 260 + 5, 4, seed=9)
+    b = gp_mod.BCM.split(X, y, K)
+    b.set_BCM_log_hyperparam(HP_DENSE)
+    rows = b.loglik_grad_rows()
+    comm = gp_mod.Comm(None, 0, 1, 0)
+    per = K + 2
+    b.set_BCM_log_hyperparam(np.array(HP_DENSE) + 0.0)
+    out = comm.loglik_grad_allgather(b, per)
+    assert out.shape == (per, 4)
+    assert np.array_equal(out[:K], rows) and np.all(out[K:] == 0.0)
+    out2 = comm.loglik_grad_allgather(b, per)                 # the handle is clean after an exchange: again, same bits
+    assert np.array_equal(out2, out)
+    L = capi.lib()
+    buf = np.zeros((per, 4))
+    assert L.cugp_bcm_loglik_grad_allgather(b._h, comm._h, K - 1 if K > 1 else 0, capi.ptr(buf)) == capi.CUGP_ERR_INVALID   # fewer slots than experts
+    h = C.c_void_p()
+    assert L.cugp_comm_create(None, 0, 0, 2, 0, C.byref(h)) == capi.CUGP_ERR_INVALID        # two ranks need an id
+    assert L.cugp_comm_create(None, 0, 3, 2, 0, C.byref(h)) == capi.CUGP_ERR_INVALID        # rank outside the world
+    idbuf = (C.c_ubyte * 64)()
+    assert L.cugp_comm_unique_id(idbuf, 64) == capi.CUGP_ERR_INVALID                        # an id is 128 bytes
+    ll, g, per_ll = b.loglik_grad()                            # the BCM still evaluates normally afterwards
+    assert np.array_equal(per_ll, rows[:, 0])
+    comm.close()
+    b.close()
+
+
 def test_second_device_after_first(gp_mod, oracle):
     """Function attributes (dynamic LDS sizes) are per device: a handle on device 1 after one on device 0."""
     import ctypes as C
